@@ -1,0 +1,192 @@
+/*
+ * rayz_hip.h — C ABI of the MI355X (gfx950) render path that replaces the loop
+ * nest of rayz's `Tracer.render()`.
+ *
+ * Every entry point cites the reference interface it stands in for
+ * (file:line into jlucier/rayz @ 2025-07-25).  The reference has no FFI of its
+ * own: its boundary is the single Zig method `Tracer.render`
+ * (src/renderer.zig:72-101).  A Zig caller copies its `MemPool` lists and its
+ * `Camera` field by field into the `extern struct`-compatible PODs below
+ * (Zig `struct`/`union(enum)` have no defined layout, so `items.ptr` cannot be
+ * passed directly), calls `rayz_hip_render`, and widens the returned f32 RGB
+ * into `img.pixels`.  See INTEGRATION.md for the Zig stub.
+ *
+ * Plain pointers and sizes only; no C++ types, exceptions or aborts cross this
+ * boundary.  All functions return RAYZ_OK (0) or a negative RayzStatus and
+ * leave a message retrievable through rayz_hip_last_error().
+ */
+#ifndef RAYZ_HIP_H
+#define RAYZ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RAYZ_HIP_ABI_VERSION 1u
+
+typedef enum RayzStatus {
+    RAYZ_OK = 0,
+    RAYZ_ERR_BAD_ARG = -1,   /* null pointer, zero size, index out of range, bad enum */
+    RAYZ_ERR_HIP = -2,       /* a HIP runtime call failed; text in rayz_hip_last_error() */
+    RAYZ_ERR_OOM = -3,       /* host or device allocation failed */
+    RAYZ_ERR_NO_DEVICE = -4, /* no usable gfx950 device / library not initialised */
+    RAYZ_ERR_STATE = -5      /* bad handle, call order */
+} RayzStatus;
+
+/* Tag order follows `Texture = union(enum){ checker, solid }`, src/material.zig:41-44. */
+typedef enum RayzTextureKind { RAYZ_TEX_CHECKER = 0, RAYZ_TEX_SOLID = 1 } RayzTextureKind;
+/* `Material = union(enum){ diffuse, metallic, dielectric }`, src/material.zig:162-165. */
+typedef enum RayzMaterialKind {
+    RAYZ_MAT_DIFFUSE = 0,
+    RAYZ_MAT_METALLIC = 1,
+    RAYZ_MAT_DIELECTRIC = 2
+} RayzMaterialKind;
+/* `DiffuseScatterMethod`, src/material.zig:67-71 (default HEMISPHERE, :74). */
+typedef enum RayzDiffuseMethod {
+    RAYZ_DIFFUSE_UNIT_SPHERE = 0,
+    RAYZ_DIFFUSE_UNIT_SPHERE_SURFACE = 1,
+    RAYZ_DIFFUSE_HEMISPHERE = 2
+} RayzDiffuseMethod;
+
+typedef enum RayzPrecision {
+    RAYZ_PRECISION_F32 = 0, /* the kernel arithmetic of DESIGN.md §4 (tmin 1e-3 recommended) */
+    RAYZ_PRECISION_F64 = 1  /* fidelity mode: the reference's own scalar type, src/vec.zig:4-8 */
+} RayzPrecision;
+
+typedef enum RayzTraversal {
+    RAYZ_TRAVERSAL_LINEAR = 0, /* flat hit list: every sphere tested per segment (north star) */
+    RAYZ_TRAVERSAL_BVH = 1     /* the reference's accelerator, src/hit.zig:101-217 */
+} RayzTraversal;
+
+/* One entry of `MemPool.textures` (src/ecs.zig:26): SolidTexture src/material.zig:19-25 or
+ * CheckerTexture src/material.zig:27-39.  `even`/`odd` are TextureHandle.idx values. */
+typedef struct RayzTexture {
+    uint32_t kind; /* RayzTextureKind */
+    uint32_t even; /* checker only */
+    uint32_t odd;  /* checker only */
+    uint32_t _pad;
+    double scale;    /* checker only */
+    double color[3]; /* solid only */
+} RayzTexture;
+
+/* One entry of `MemPool.materials` (src/ecs.zig:25): DiffuseMaterial src/material.zig:73-75,
+ * MetallicMaterial :104-106, DielectricMaterial :134-135. */
+typedef struct RayzMaterial {
+    uint32_t kind;    /* RayzMaterialKind */
+    uint32_t texture; /* TextureHandle.idx (diffuse, metallic) */
+    uint32_t method;  /* RayzDiffuseMethod (diffuse) */
+    uint32_t _pad;
+    double param;     /* metallic: fuzz; dielectric: refractive_index */
+} RayzMaterial;
+
+/* One entry of `MemPool.spheres` (src/ecs.zig:24): `Sphere{center: Ray, radius, material}`,
+ * src/geom.zig:11-14.  `center` = center.origin, `velocity` = center.dir (center.time unused). */
+typedef struct RayzSphere {
+    double center[3];
+    double velocity[3];
+    double radius;
+    uint32_t material; /* MaterialHandle.idx */
+    uint32_t _pad;
+} RayzSphere;
+
+/* The three `MemPool` lists (src/ecs.zig:22-27), borrowed for the duration of the call. */
+typedef struct RayzSceneDesc {
+    const RayzSphere* spheres;
+    const RayzMaterial* materials;
+    const RayzTexture* textures;
+    uint32_t n_spheres;
+    uint32_t n_materials;
+    uint32_t n_textures;
+    uint32_t _pad;
+} RayzSceneDesc;
+
+/* The fields of `Camera` AFTER `Camera.init` (src/camera.zig:9-16): results, not look-at params. */
+typedef struct RayzCameraDesc {
+    double look_from[3];
+    double px_du[3];
+    double px_dv[3];
+    double px_origin[3];
+    double defocus_u[3];
+    double defocus_v[3];
+    uint32_t defocus; /* bool */
+    uint32_t _pad;
+} RayzCameraDesc;
+
+/* `Tracer` fields that steer render() (src/renderer.zig:18-28) plus what the reference lacks:
+ * a settable seed (it seeds from getrandom, :55-59), an explicit tmin (hard-coded 1e-10 at :107),
+ * the precision/traversal selectors and the row-tile shard for multi-GPU. */
+typedef struct RayzRenderParams {
+    uint32_t width;  /* img.w, src/image.zig:6 */
+    uint32_t height; /* img.h, src/image.zig:5 */
+    uint32_t samples_per_px; /* src/renderer.zig:24 */
+    uint32_t max_bounces;    /* src/renderer.zig:23 */
+    uint64_t seed;           /* key of the per-(pixel,sample) PCG32 streams */
+    double tmin;             /* src/renderer.zig:107 passes 1e-10 */
+    uint32_t precision;      /* RayzPrecision */
+    uint32_t traversal;      /* RayzTraversal */
+    uint32_t chunk_spp;      /* samples summed per work item, 0 = 16; part of the image's definition
+                                (fixes the f32 summation tree) */
+    uint32_t tile_rows;      /* rows per shard tile, 0 = 8 */
+    uint32_t shard_index;    /* this call renders rows with (row / tile_rows) % shard_count == shard_index */
+    uint32_t shard_count;    /* 0 or 1 = whole image */
+} RayzRenderParams;
+
+/* What `render()` returns (primary rays, src/renderer.zig:90,100) plus the counts the roofline needs. */
+typedef struct RayzRenderStats {
+    uint64_t primary_rays; /* rows_in_shard * width * samples_per_px */
+    uint64_t segments;     /* findHit calls: one per ray segment, src/renderer.zig:107 */
+    uint64_t sphere_tests; /* Sphere.hitInner evaluations, src/geom.zig:38-66 */
+    uint64_t node_tests;   /* AABB.hit evaluations (BVH traversal only), src/hit.zig:70-98 */
+    double kernel_ms;      /* HIP-event time of the trace kernel(s) of the last render on this scene */
+} RayzRenderStats;
+
+typedef struct RayzScene RayzScene; /* opaque: device-resident scene + workspace */
+
+/* Library / device lifetime.  `device` is the HIP ordinal this process renders on
+ * (one process per GPU).  Idempotent. */
+int rayz_hip_init(int device);
+void rayz_hip_shutdown(void);
+const char* rayz_hip_last_error(void);
+uint32_t rayz_hip_abi_version(void);
+
+/* Number of rows the shard described by `p` owns (= rows of the compact output). */
+uint32_t rayz_hip_shard_rows(const RayzRenderParams* p);
+
+/* Replaces src/renderer.zig:76-78 (initHittables + BVH build) and what follows it: validates the
+ * handles, lays the pool out in HBM and (for BVH traversal) builds the reference's BVH on the host. */
+int rayz_hip_scene_create(const RayzSceneDesc* scene, RayzScene** out);
+int rayz_hip_scene_destroy(RayzScene* scene);
+
+/* Replaces the loop nest src/renderer.zig:80-97.  Asynchronous on `hip_stream` (a hipStream_t, or
+ * NULL for the library's own stream); `d_rgb_out` is DEVICE memory, rows_in_shard*width*3 floats,
+ * row-major packed RGB, linear radiance means as `img.pixels` holds them (src/renderer.zig:94-95;
+ * no gamma or clamp, those live in writePPM, src/image.zig:29-41). */
+int rayz_hip_render_device(RayzScene* scene, const RayzCameraDesc* camera, const RayzRenderParams* params,
+                           float* d_rgb_out, void* hip_stream);
+
+/* Same, f64 output (precision F64): rows_in_shard*width*3 doubles. */
+int rayz_hip_render_device_f64(RayzScene* scene, const RayzCameraDesc* camera, const RayzRenderParams* params,
+                               double* d_rgb_out, void* hip_stream);
+
+/* Waits for the last render on `scene` and returns its counters. */
+int rayz_hip_scene_sync(RayzScene* scene, RayzRenderStats* stats_or_null);
+
+/* Blocking one-shot form of `tracer.render()` as main() calls it (src/rayz.zig:26): upload, render,
+ * download into caller-owned host memory (`rgb_out`: rows_in_shard*width*3 floats). */
+int rayz_hip_render(const RayzSceneDesc* scene, const RayzCameraDesc* camera, const RayzRenderParams* params,
+                    float* rgb_out, RayzRenderStats* stats_or_null);
+int rayz_hip_render_f64(const RayzSceneDesc* scene, const RayzCameraDesc* camera, const RayzRenderParams* params,
+                        double* rgb_out, RayzRenderStats* stats_or_null);
+
+/* The step after the path, `Image.writePPM`'s per-pixel transform (src/image.zig:35-38,
+ * src/vec.zig:79-93): sqrt-gamma, clamp to [0,1], truncate x*255 to u8.  Device to device,
+ * n_pixels*3 floats in, n_pixels*3 bytes out. */
+int rayz_hip_tonemap_u8(const float* d_rgb, uint8_t* d_rgb8, size_t n_pixels, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAYZ_HIP_H */

@@ -1,0 +1,1193 @@
+// rayz_oracle.cpp — CPU restatement of jlucier/rayz's `Tracer.render()` path.
+//
+// TEST INFRASTRUCTURE ONLY.  Nothing under rayz_amd/ may include, link, load or call this file;
+// only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do, as the checker.
+//
+// Parity status: the reference is Zig and cannot be built in this image (no zig toolchain), its
+// seed comes from getrandom and is never printed (src/renderer.zig:55-59), and none of its own
+// tests covers hitInner, scatter, bounceRay or a rendered image.  The functions the
+// reference DOES test are pinned by tests/test_oracle_kat.py against those vectors (refract
+// src/material.zig:213-223, get ray src/renderer.zig:129-149, sphere bbox src/geom.zig:69-84,
+// AABB src/hit.zig:237-279, V3 src/vec.zig:169-215, utils src/utils.zig:15-32).  The rendered image
+// and the RNG stream (Zig std, not under /root/reference) are "parity unpinned" against the real
+// reference; mode A below is a line-by-line restatement instead.
+//
+// Two modes:
+//   mode A — the reference as written: f64, one sequential xoshiro256++ stream (Zig DefaultPrng),
+//            recursive BVH build + traversal, recursive bounceRay, tmin as given (1e-10 there).
+//            No FMA contraction (built with -ffp-contract=off).  It is the CPU baseline.
+//   mode B — the arithmetic the HIP kernel is specified to perform: real = f32 or
+//            f64, one PCG32 stream per (pixel, sample), iterative bounce loop, flat hit list in
+//            device order (static spheres, then moving ones), explicit fma in stated places; the
+//            per-sphere reject test runs in `real`, an accepted candidate's roots are computed in
+//            f64 from the pool's f64 sphere (no f32 self-intersection on the r=1000 ground).
+//            The HIP path must reproduce mode B bit for bit.
+//
+// All file:line citations are into /root/reference (jlucier/rayz @ 2025-07-25).
+
+#include "../include/rayz_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// RNGs
+// ------------------------------------------------------------------------------------------------
+
+// Zig std.Random.SplitMix64 (Vigna's splitmix64; third-party to the reference, see header).
+struct SplitMix64 {
+    u64 s;
+    u64 next() {
+        s += 0x9e3779b97f4a7c15ull;
+        u64 z = s;
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+        return z ^ (z >> 31);
+    }
+};
+
+static inline u64 rotl64(u64 x, int k) { return (x << k) | (x >> (64 - k)); }
+
+// Zig std.Random.DefaultPrng = Xoshiro256 (xoshiro256++), seeded through SplitMix64.
+// Call sites: src/renderer.zig:22,55-59.
+struct Xoshiro256pp {
+    u64 s[4];
+    void seed(u64 v) {
+        SplitMix64 g{v};
+        for (int i = 0; i < 4; ++i) s[i] = g.next();
+    }
+    u64 next() {
+        const u64 r = rotl64(s[0] + s[3], 23) + s[0];
+        const u64 t = s[1] << 17;
+        s[2] ^= s[0];
+        s[3] ^= s[1];
+        s[1] ^= s[2];
+        s[0] ^= s[3];
+        s[2] ^= t;
+        s[3] = rotl64(s[3], 45);
+        return r;
+    }
+    // Zig 0.13/0.14 std.Random.float(f64): 52 mantissa bits from one u64, exponent from its
+    // leading-zero count (restated from memory of Zig std; source not in the container).
+    double float64() {
+        const u64 r = next();
+        unsigned lz = r ? (unsigned)__builtin_clzll(r) : 64u;
+        if (lz >= 12) {
+            lz = 12;
+            for (;;) {
+                const u64 a = next();
+                const unsigned alz = a ? (unsigned)__builtin_clzll(a) : 64u;
+                lz += alz;
+                if (alz != 64) break;
+                if (lz >= 1022) {
+                    lz = 1022;
+                    break;
+                }
+            }
+        }
+        const u64 mant = r & 0xFFFFFFFFFFFFFull;
+        const u64 expo = (u64)(1022 - lz) << 52;
+        const u64 bits = expo | mant;
+        double d;
+        std::memcpy(&d, &bits, 8);
+        return d;
+    }
+};
+
+// PCG32 (O'Neill, XSH-RR 64/32), one stream per path.  DESIGN.md §4.1.
+static inline u64 mix64(u64 z) {
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+struct Pcg32 {
+    u64 state, inc;
+    void srandom(u64 initstate, u64 initseq) {
+        state = 0;
+        inc = (initseq << 1) | 1u;
+        next();
+        state += initstate;
+        next();
+    }
+    u32 next() {
+        const u64 old = state;
+        state = old * 6364136223846793005ull + inc;
+        const u32 xorshifted = (u32)(((old >> 18u) ^ old) >> 27u);
+        const u32 rot = (u32)(old >> 59u);
+        return (xorshifted >> rot) | (xorshifted << ((32u - rot) & 31u));
+    }
+    // key of path (pixel_index, sample): DESIGN.md §4.1
+    void seed_path(u64 seed, u64 path_id) {
+        const u64 a = mix64(seed + (path_id + 1) * 0x9e3779b97f4a7c15ull);
+        const u64 b = mix64(a + 0x9e3779b97f4a7c15ull);
+        srandom(a, b);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Mode A — the reference as written (f64)
+// ------------------------------------------------------------------------------------------------
+namespace A {
+
+// src/vec.zig:4-157
+struct V3 {
+    double x = 0, y = 0, z = 0;
+    static V3 of(double v) { return {v, v, v}; }
+    double at(int ax) const { return ax == 0 ? x : (ax == 1 ? y : z); }      // :26-33
+    V3 add(V3 o) const { return {x + o.x, y + o.y, z + o.z}; }               // :47-53
+    V3 sub(V3 o) const { return {x - o.x, y - o.y, z - o.z}; }               // :55-61
+    V3 mul(double v) const { return {x * v, y * v, z * v}; }                 // :63-65
+    V3 div(double v) const { return mul(1 / v); }                            // :67-69
+    double dot(V3 o) const { return x * o.x + y * o.y + z * o.z; }           // :95-97
+    double mag() const { return std::sqrt(dot(*this)); }                     // :71-73
+    V3 unit() const { return div(mag()); }                                   // :75-77
+    V3 cross(V3 o) const {                                                   // :99-105
+        return {y * o.z - z * o.y, z * o.x - x * o.z, x * o.y - y * o.x};
+    }
+    bool nearZero() const {                                                  // :107-110
+        const double tol = 1e-8;
+        return std::fabs(x) <= tol && std::fabs(y) <= tol && std::fabs(z) <= tol;
+    }
+    bool close(V3 o) const { return sub(o).nearZero(); }                     // :112-114
+    V3 vmul(V3 o) const { return {x * o.x, y * o.y, z * o.z}; }              // :118-124
+    V3 vdiv(V3 o) const { return {x / o.x, y / o.y, z / o.z}; }              // :126-132
+    V3 vmin(V3 o) const { return {std::fmin(x, o.x), std::fmin(y, o.y), std::fmin(z, o.z)}; } // :134-140
+    V3 vmax(V3 o) const { return {std::fmax(x, o.x), std::fmax(y, o.y), std::fmax(z, o.z)}; } // :142-148
+    int amax() const {                                                       // :150-156
+        if (x > y) return x > z ? 0 : 2;
+        return y > z ? 1 : 2;
+    }
+    V3 sqrt() const {                                                        // :87-93
+        return {x > 0 ? std::sqrt(x) : 0, y > 0 ? std::sqrt(y) : 0, z > 0 ? std::sqrt(z) : 0};
+    }
+    V3 clamp(double lo, double hi) const {                                   // :79-85, src/utils.zig:3-13
+        auto c = [&](double v) {
+            const double m = v > lo ? v : lo;
+            return m < hi ? m : hi;
+        };
+        return {c(x), c(y), c(z)};
+    }
+};
+static V3 v3(const double* p) { return {p[0], p[1], p[2]}; }
+static V3 v3random(Xoshiro256pp& r, double lo, double hi) {                  // src/vec.zig:9-16
+    const double scale = hi - lo;
+    V3 v;
+    v.x = r.float64() * scale + lo;
+    v.y = r.float64() * scale + lo;
+    v.z = r.float64() * scale + lo;
+    return v;
+}
+
+struct Ray {                                                                 // src/vec.zig:159-167
+    V3 origin, dir;
+    double time = 0;
+    V3 at(double t) const { return origin.add(dir.mul(t)); }
+};
+
+struct AABB {                                                                // src/hit.zig:44-99
+    V3 low = V3::of(std::numeric_limits<double>::infinity());
+    V3 high = V3::of(-std::numeric_limits<double>::infinity());
+    static AABB init(V3 a, V3 b) { return {a.vmin(b), a.vmax(b)}; }
+    static AABB enclose(const AABB& a, const AABB& b) { return {a.low.vmin(b.low), a.high.vmax(b.high)}; }
+    int longestAxis() const { return high.sub(low).amax(); }
+    bool hit(const Ray& ray, double tmin, double tmax) const {               // :70-98
+        const V3 t0s = low.sub(ray.origin).vdiv(ray.dir);
+        const V3 t1s = high.sub(ray.origin).vdiv(ray.dir);
+        double t0 = tmin, t1 = tmax;
+        for (int ax = 0; ax < 3; ++ax) {
+            const double v0 = t0s.at(ax), v1 = t1s.at(ax);
+            if (v0 < v1) {
+                t0 = std::fmax(v0, t0);
+                t1 = std::fmin(v1, t1);
+            } else {
+                t0 = std::fmax(v1, t0);
+                t1 = std::fmin(v0, t1);
+            }
+        }
+        return t1 > t0;
+    }
+};
+
+struct Hit {                                                                 // src/hit.zig:16-42
+    V3 point, normal;
+    double t = 0;
+    bool front_face = false;
+    u32 material = 0;
+    bool valid = false;
+    static Hit init(const Ray& ray, V3 point, V3 normal, double t, u32 material) {
+        Hit h;
+        h.front_face = normal.dot(ray.dir) < 0;
+        h.point = point;
+        h.normal = h.front_face ? normal : normal.mul(-1);
+        h.t = t;
+        h.material = material;
+        h.valid = true;
+        return h;
+    }
+};
+
+struct Sphere {                                                              // src/geom.zig:11-67
+    Ray center;
+    double radius;
+    u32 material;
+    AABB boundingBox() const {                                               // :24-31
+        const V3 rad = V3::of(radius);
+        const V3 o1 = center.origin, o2 = center.at(1);
+        return AABB::enclose(AABB::init(o1.sub(rad), o1.add(rad)), AABB::init(o2.sub(rad), o2.add(rad)));
+    }
+    Hit hitInner(const Ray& ray, double tmin, double tmax) const {           // :38-66
+        const V3 origin_now = center.at(ray.time);
+        const V3 offset = origin_now.sub(ray.origin);
+        const double a = ray.dir.dot(ray.dir);
+        const double half_b = ray.dir.dot(offset);
+        const double c = offset.dot(offset) - radius * radius;
+        const double disc = half_b * half_b - a * c;
+        if (disc < 0) return Hit{};
+        const double rt = std::sqrt(disc);
+        const double t1 = (half_b - rt) / a, t2 = (half_b + rt) / a;
+        double t;
+        if (t1 >= tmin && t1 <= tmax) t = t1;
+        else if (t2 >= tmin && t2 <= tmax) t = t2;
+        else return Hit{};
+        const V3 point = ray.at(t);
+        const V3 n = point.sub(origin_now).unit();
+        return Hit::init(ray, point, n, t, material);
+    }
+};
+
+struct Hittable {                                                            // src/hit.zig:8-12
+    AABB bbox;
+    u32 sphere;
+};
+
+struct Counters {
+    u64 segments = 0, sphere_tests = 0, node_tests = 0;
+};
+
+struct Scene {
+    std::vector<Sphere> spheres;
+    std::vector<RayzMaterial> materials;
+    std::vector<RayzTexture> textures;
+    std::vector<Hittable> hittables;
+};
+
+struct BVH {                                                                 // src/hit.zig:101-217
+    struct Node {
+        AABB bbox;
+        size_t starti = 0, endi = 0;
+        int left = -1, right = -1;
+    };
+    std::vector<Node> nodes;
+    int build(std::vector<Hittable>& h, size_t si, size_t ei) {              // :130-161
+        const int me = (int)nodes.size();
+        nodes.push_back(Node{});
+        const size_t nobjs = ei - si;
+        AABB bb;
+        for (size_t i = si; i < ei; ++i) bb = AABB::enclose(bb, h[i].bbox);
+        nodes[me].bbox = bb;
+        if (nobjs <= 2) {
+            nodes[me].starti = si;
+            nodes[me].endi = ei;
+        } else {
+            const int ax = bb.longestAxis();
+            // std.mem.sort is a stable sort (Zig std block sort)
+            std::stable_sort(h.begin() + si, h.begin() + ei, [ax](const Hittable& a, const Hittable& b) {
+                return a.bbox.low.at(ax) < b.bbox.low.at(ax);
+            });
+            const size_t mid = nobjs / 2 + si;
+            const int l = build(h, si, mid);
+            const int r = build(h, mid, ei);
+            nodes[me].left = l;
+            nodes[me].right = r;
+        }
+        return me;
+    }
+    Hit findHit(int ni, const Scene& sc, const Ray& ray, double tmin, double tmax, Counters& c) const { // :181-216
+        const Node& n = nodes[ni];
+        c.node_tests++;
+        if (!n.bbox.hit(ray, tmin, tmax)) return Hit{};
+        Hit maybe;
+        if (n.left >= 0) {
+            maybe = findHit(n.left, sc, ray, tmin, tmax, c);
+            const double maxt = maybe.valid ? maybe.t : tmax;
+            const Hit nh = findHit(n.right, sc, ray, tmin, maxt, c);
+            if (nh.valid) maybe = nh;
+            return maybe;
+        }
+        for (size_t i = n.starti; i < n.endi; ++i) {
+            const double maxt = maybe.valid ? maybe.t : tmax;
+            c.sphere_tests++;
+            const Hit nh = sc.spheres[sc.hittables[i].sphere].hitInner(ray, tmin, maxt);
+            if (nh.valid) maybe = nh;
+        }
+        return maybe;
+    }
+};
+
+// src/material.zig:19-51
+static V3 textureValue(const Scene& sc, u32 idx, V3 point) {
+    const RayzTexture& t = sc.textures[idx];
+    if (t.kind == RAYZ_TEX_SOLID) return v3(t.color);
+    const int64_t x = (int64_t)std::floor(point.x / t.scale);
+    const int64_t y = (int64_t)std::floor(point.y / t.scale);
+    const int64_t z = (int64_t)std::floor(point.z / t.scale);
+    const int64_t s = x + y + z;
+    const int64_t m = ((s % 2) + 2) % 2; // @mod: floored
+    return textureValue(sc, m == 0 ? t.even : t.odd, point);
+}
+
+static V3 randomInUnitSphere(Xoshiro256pp& r) {                              // src/material.zig:196-202
+    for (;;) {
+        const V3 v = v3random(r, -1, 1);
+        if (v.mag() <= 1) return v;
+    }
+}
+static V3 randomUnit(Xoshiro256pp& r) { return randomInUnitSphere(r).unit(); }      // :204-206
+static V3 randomInHemisphere(Xoshiro256pp& r, V3 n) {                        // :208-211
+    const V3 v = randomInUnitSphere(r);
+    return v.dot(n) > 0 ? v : v.mul(-1);
+}
+static double reflectance(double cos, double ri) {                           // :179-183
+    double r0 = (1 - ri) / (1 + ri);
+    r0 *= r0;
+    return r0 + (1 - r0) * std::pow(1 - cos, 5);
+}
+static V3 reflect(const Ray& ray, const Hit& hit) {                          // :185-187
+    return ray.dir.sub(hit.normal.mul(2 * ray.dir.dot(hit.normal)));
+}
+static V3 refract(V3 unit_dir, V3 norm, double eta) {                        // :189-194
+    const double cos_theta = unit_dir.mul(-1).dot(norm);
+    const V3 perp = norm.mul(cos_theta).add(unit_dir).mul(eta);
+    const V3 par = norm.mul(-std::sqrt(1 - perp.dot(perp)));
+    return perp.add(par);
+}
+
+struct Scatter {
+    bool ok = false;
+    Ray ray;
+    V3 att;
+};
+
+static Scatter scatter(const Scene& sc, const RayzMaterial& m, Xoshiro256pp& rng, const Ray& ray, const Hit& hit) {
+    Scatter s;
+    if (m.kind == RAYZ_MAT_DIFFUSE) {                                        // src/material.zig:77-101
+        V3 target;
+        if (m.method == RAYZ_DIFFUSE_UNIT_SPHERE) target = hit.point.add(hit.normal).add(randomInUnitSphere(rng));
+        else if (m.method == RAYZ_DIFFUSE_UNIT_SPHERE_SURFACE) target = hit.point.add(hit.normal).add(randomUnit(rng));
+        else target = hit.point.add(randomInHemisphere(rng, hit.normal));
+        if (target.nearZero()) target = hit.normal;
+        s.ok = true;
+        s.ray.origin = hit.point;
+        s.ray.dir = target.sub(hit.point);
+        s.ray.time = ray.time;
+        s.att = textureValue(sc, m.texture, hit.point);
+    } else if (m.kind == RAYZ_MAT_METALLIC) {                                // :108-131
+        V3 d = reflect(ray, hit).unit();
+        if (m.param > 0) d = d.add(randomUnit(rng).mul(std::fmin(m.param, 1.0)));
+        if (d.dot(hit.normal) <= 0) return s;
+        s.ok = true;
+        s.ray.origin = hit.point;
+        s.ray.dir = d;
+        s.ray.time = ray.time;
+        s.att = textureValue(sc, m.texture, hit.point);
+    } else {                                                                 // :137-159
+        const double eta = hit.front_face ? 1 / m.param : m.param;
+        const V3 ud = ray.dir.unit();
+        const double cos_theta = ud.mul(-1).dot(hit.normal);
+        const double sin_theta = std::sqrt(1 - cos_theta * cos_theta);
+        V3 dir;
+        if (eta * sin_theta > 1.0 || reflectance(cos_theta, eta) > rng.float64()) dir = reflect(ray, hit);
+        else dir = refract(ud, hit.normal, eta);
+        s.ok = true;
+        s.ray.origin = hit.point;
+        s.ray.dir = dir;
+        s.ray.time = ray.time;
+        s.att = V3::of(1);
+    }
+    return s;
+}
+
+struct Camera {                                                              // src/camera.zig:8-91
+    V3 look_from, px_du, px_dv, px_origin, defocus_u, defocus_v;
+    bool defocus = false;
+    static Camera init(double vfov, double focus_dist, double defocus_angle, V3 look_from, V3 look_at, V3 vup,
+                       size_t img_h, size_t img_w) {                         // :18-57
+        const double DEG = M_PI / 180.0;
+        const double fh = (double)img_h, fw = (double)img_w;
+        const double vp_h = 2 * std::tan(vfov * DEG / 2.0) * focus_dist;
+        const double vp_w = vp_h * fw / fh;
+        const V3 w = look_from.sub(look_at).unit();
+        const V3 u = vup.cross(w).unit();
+        const V3 v = w.cross(u);
+        const V3 vp_u = u.mul(vp_w), vp_v = v.mul(-vp_h);
+        const V3 px_du = vp_u.div(fw), px_dv = vp_v.div(fh);
+        const double dr = std::tan(defocus_angle * DEG / 2) * focus_dist;
+        const V3 vp_origin =
+            look_from.sub(w.mul(focus_dist)).sub(vp_u.div(2)).sub(vp_v.div(2)).add(px_du.add(px_dv).mul(0.5));
+        Camera c;
+        c.look_from = look_from;
+        c.px_du = px_du;
+        c.px_dv = px_dv;
+        c.px_origin = vp_origin;
+        c.defocus_u = u.mul(dr);
+        c.defocus_v = v.mul(dr);
+        c.defocus = defocus_angle > 0;
+        return c;
+    }
+    V3 randomInDefocus(Xoshiro256pp& r) const {                              // :79-90
+        if (!defocus) return V3{};
+        for (;;) {
+            V3 v;
+            v.x = r.float64() * 2 - 1;
+            v.y = r.float64() * 2 - 1;
+            v.z = 0;
+            if (v.dot(v) <= 1) return defocus_u.mul(v.x).add(defocus_v.mul(v.y));
+        }
+    }
+    Ray getRay(size_t px, size_t py, Xoshiro256pp* r) const {                // :59-77
+        double x = (double)px, y = (double)py;
+        V3 origin = look_from;
+        if (r) {
+            x += r->float64() - 0.5;
+            y += r->float64() - 0.5;
+            origin = origin.add(randomInDefocus(*r));
+        }
+        Ray ray;
+        ray.dir = px_du.mul(x).add(px_dv.mul(y)).add(px_origin).sub(origin);
+        ray.origin = origin;
+        ray.time = r ? r->float64() : 0;
+        return ray;
+    }
+};
+
+static Camera cameraFrom(const RayzCameraDesc& d) {
+    Camera c;
+    c.look_from = v3(d.look_from);
+    c.px_du = v3(d.px_du);
+    c.px_dv = v3(d.px_dv);
+    c.px_origin = v3(d.px_origin);
+    c.defocus_u = v3(d.defocus_u);
+    c.defocus_v = v3(d.defocus_v);
+    c.defocus = d.defocus != 0;
+    return c;
+}
+static void cameraTo(const Camera& c, RayzCameraDesc* d) {
+    auto put = [](double* p, V3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; };
+    put(d->look_from, c.look_from);
+    put(d->px_du, c.px_du);
+    put(d->px_dv, c.px_dv);
+    put(d->px_origin, c.px_origin);
+    put(d->defocus_u, c.defocus_u);
+    put(d->defocus_v, c.defocus_v);
+    d->defocus = c.defocus ? 1u : 0u;
+    d->_pad = 0;
+}
+
+struct Tracer {                                                              // src/renderer.zig:18-126
+    Scene sc;
+    BVH bvh;
+    Camera cam;
+    Xoshiro256pp rng;
+    double tmin = 1e-10;
+    bool linear = false;
+    Counters cnt;
+
+    Hit findHit(const Ray& ray) {
+        cnt.segments++;
+        const double inf = std::numeric_limits<double>::infinity();
+        if (sc.hittables.empty()) return Hit{};
+        if (!linear) return bvh.findHit(0, sc, ray, tmin, inf, cnt);
+        // flat hit list: same acceptance rule as a BVH leaf (src/hit.zig:208-214) over all hittables
+        Hit maybe;
+        for (size_t i = 0; i < sc.hittables.size(); ++i) {
+            const double maxt = maybe.valid ? maybe.t : inf;
+            cnt.sphere_tests++;
+            const Hit nh = sc.spheres[sc.hittables[i].sphere].hitInner(ray, tmin, maxt);
+            if (nh.valid) maybe = nh;
+        }
+        return maybe;
+    }
+    V3 bounceRay(const Ray& ray, size_t depth) {                             // :103-126
+        if (depth == 0) return V3{};
+        const Hit hit = findHit(ray);
+        if (hit.valid) {
+            V3 ret;
+            const RayzMaterial& m = sc.materials[hit.material];
+            const Scatter s = scatter(sc, m, rng, ray, hit);
+            if (s.ok) ret = bounceRay(s.ray, depth - 1).vmul(s.att);
+            return ret;
+        }
+        const double t = 0.5 * (ray.dir.unit().y + 1.0);
+        return V3::of(1).mul(1.0 - t).add(V3{0.5, 0.7, 1.0}).mul(t);
+    }
+};
+
+} // namespace A
+
+// ------------------------------------------------------------------------------------------------
+// Mode B — the kernel arithmetic, real = float | double
+// ------------------------------------------------------------------------------------------------
+namespace B {
+
+template <class R> struct V {
+    R x, y, z;
+};
+template <class R> static inline R fm(R a, R b, R c) { return std::fma(a, b, c); }
+template <class R> static inline R dot3(V<R> a, V<R> b) { return fm(a.z, b.z, fm(a.y, b.y, a.x * b.x)); }
+template <class R> static inline V<R> scale(V<R> a, R s) { return {a.x * s, a.y * s, a.z * s}; }
+template <class R> static inline V<R> neg(V<R> a) { return {-a.x, -a.y, -a.z}; }
+template <class R> static inline V<R> unit(V<R> a) {
+    const R m = std::sqrt(dot3(a, a));
+    const R inv = R(1) / m;
+    return scale(a, inv);
+}
+
+template <class R> struct Rng {
+    Pcg32 g;
+    R uniform();
+};
+template <> inline float Rng<float>::uniform() { return (float)(g.next() >> 8) * 0x1p-24f; }
+template <> inline double Rng<double>::uniform() { return (double)g.next() * 0x1p-32; }
+
+template <class R> struct Tex {
+    u32 kind, even, odd;
+    R scale;
+    V<R> color;
+};
+template <class R> struct Mat {
+    u32 kind, texture, method;
+    R param;     // fuzz | ior
+    R inv_param; // 1/ior
+};
+template <class R> struct Sph {
+    V<R> c;     // broad phase, narrowed to R
+    R r2;
+    V<R> v;
+    double c64[3], v64[3], r2_64; // narrow phase: the pool's own f64 values
+    u32 mat;
+};
+template <class R> struct SceneB {
+    std::vector<Sph<R>> sph; // device order: static spheres (pool order), then moving spheres (pool order)
+    u32 n_static = 0;
+    std::vector<Mat<R>> mats;
+    std::vector<Tex<R>> texs;
+};
+template <class R> struct CamB {
+    V<R> from, du, dv, pxo, defu, defv;
+    bool defocus;
+};
+
+template <class R> static V<R> narrow3(const double* p) { return {(R)p[0], (R)p[1], (R)p[2]}; }
+
+template <class R> static SceneB<R> buildScene(const RayzSceneDesc& d) {
+    SceneB<R> s;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (u32 i = 0; i < d.n_spheres; ++i) {
+            const RayzSphere& q = d.spheres[i];
+            const bool moving = q.velocity[0] != 0 || q.velocity[1] != 0 || q.velocity[2] != 0;
+            if ((pass == 1) != moving) continue;
+            Sph<R> o;
+            o.c = narrow3<R>(q.center);
+            o.v = narrow3<R>(q.velocity);
+            const R r = (R)q.radius;
+            o.r2 = r * r;
+            for (int k = 0; k < 3; ++k) o.c64[k] = q.center[k], o.v64[k] = q.velocity[k];
+            o.r2_64 = q.radius * q.radius;
+            o.mat = q.material;
+            s.sph.push_back(o);
+        }
+        if (pass == 0) s.n_static = (u32)s.sph.size();
+    }
+    for (u32 i = 0; i < d.n_materials; ++i) {
+        const RayzMaterial& m = d.materials[i];
+        Mat<R> o;
+        o.kind = m.kind;
+        o.texture = m.texture;
+        o.method = m.method;
+        o.param = (R)m.param;
+        o.inv_param = R(1) / o.param;
+        s.mats.push_back(o);
+    }
+    for (u32 i = 0; i < d.n_textures; ++i) {
+        const RayzTexture& t = d.textures[i];
+        Tex<R> o;
+        o.kind = t.kind;
+        o.even = t.even;
+        o.odd = t.odd;
+        o.scale = (R)t.scale;
+        o.color = narrow3<R>(t.color);
+        s.texs.push_back(o);
+    }
+    return s;
+}
+
+template <class R> static CamB<R> buildCamera(const RayzCameraDesc& d) {
+    CamB<R> c;
+    c.from = narrow3<R>(d.look_from);
+    c.du = narrow3<R>(d.px_du);
+    c.dv = narrow3<R>(d.px_dv);
+    c.pxo = narrow3<R>(d.px_origin);
+    c.defu = narrow3<R>(d.defocus_u);
+    c.defv = narrow3<R>(d.defocus_v);
+    c.defocus = d.defocus != 0;
+    return c;
+}
+
+static const int kMaxRejectionTries = 64;
+static const int kMaxTextureDepth = 8;
+
+template <class R> static V<R> randomInUnitSphere(Rng<R>& g) {               // src/material.zig:196-202
+    V<R> v{0, 0, 0};
+    for (int i = 0; i < kMaxRejectionTries; ++i) {
+        v.x = fm(g.uniform(), R(2), R(-1));                                  // V3.random x,y,z order, src/vec.zig:9-16
+        v.y = fm(g.uniform(), R(2), R(-1));
+        v.z = fm(g.uniform(), R(2), R(-1));
+        if (std::sqrt(dot3(v, v)) <= R(1)) break;
+    }
+    return v;
+}
+
+template <class R> static V<R> textureValue(const SceneB<R>& sc, u32 idx, V<R> p) { // src/material.zig:19-51
+    for (int depth = 0; depth < kMaxTextureDepth; ++depth) {
+        const Tex<R>& t = sc.texs[idx];
+        if (t.kind == RAYZ_TEX_SOLID) return t.color;
+        const R lim = R(1073741824.0);
+        auto cell = [&](R c) {
+            R f = std::floor(c / t.scale);
+            f = f < -lim ? -lim : f;
+            f = f > lim ? lim : f;
+            return (int32_t)f;
+        };
+        const int32_t s = (int32_t)((u32)cell(p.x) + (u32)cell(p.y) + (u32)cell(p.z));
+        idx = (s & 1) == 0 ? t.even : t.odd;
+    }
+    return V<R>{0, 0, 0};
+}
+
+template <class R> struct PathResult {
+    V<R> L;
+    u32 segments;
+};
+
+template <class R>
+static PathResult<R> tracePath(const SceneB<R>& sc, const CamB<R>& cam, const RayzRenderParams& p, u32 px, u32 py,
+                               u32 s) {
+    const R tmin = (R)p.tmin;
+    Rng<R> g;
+    const u64 pixel_index = (u64)py * p.width + px;
+    g.g.seed_path(p.seed, pixel_index * p.samples_per_px + s);
+
+    // --- camera ray, src/camera.zig:59-77 ---
+    const R x = (R)px + (g.uniform() - R(0.5));
+    const R y = (R)py + (g.uniform() - R(0.5));
+    V<R> o = cam.from;
+    if (cam.defocus) {                                                       // :79-90
+        R vx = 0, vy = 0;
+        for (int i = 0; i < kMaxRejectionTries; ++i) {
+            vx = fm(g.uniform(), R(2), R(-1));
+            vy = fm(g.uniform(), R(2), R(-1));
+            if (fm(vy, vy, vx * vx) <= R(1)) break;
+        }
+        o.x = cam.from.x + fm(cam.defv.x, vy, cam.defu.x * vx);
+        o.y = cam.from.y + fm(cam.defv.y, vy, cam.defu.y * vx);
+        o.z = cam.from.z + fm(cam.defv.z, vy, cam.defu.z * vx);
+    }
+    V<R> d;
+    d.x = (fm(cam.dv.x, y, cam.du.x * x) + cam.pxo.x) - o.x;
+    d.y = (fm(cam.dv.y, y, cam.du.y * x) + cam.pxo.y) - o.y;
+    d.z = (fm(cam.dv.z, y, cam.du.z * x) + cam.pxo.z) - o.z;
+    const R time = g.uniform();
+
+    V<R> thr{1, 1, 1};
+    PathResult<R> res{{0, 0, 0}, 0};
+    const R inf = std::numeric_limits<R>::infinity();
+
+    for (u32 seg = 0; seg < p.max_bounces; ++seg) {                          // src/renderer.zig:103-126, iterative
+        res.segments++;
+        // --- nearest hit over the flat list, src/geom.zig:38-66 per sphere ---
+        const R a = dot3(d, d);
+        R tbest = inf;
+        int ibest = -1;
+        const u32 n = (u32)sc.sph.size();
+        for (u32 i = 0; i < n; ++i) {
+            const Sph<R>& q = sc.sph[i];
+            R ocx = q.c.x - o.x, ocy = q.c.y - o.y, ocz = q.c.z - o.z;
+            if (i >= sc.n_static) {
+                ocx = fm(q.v.x, time, ocx);
+                ocy = fm(q.v.y, time, ocy);
+                ocz = fm(q.v.z, time, ocz);
+            }
+            const R hb = fm(d.z, ocz, fm(d.y, ocy, d.x * ocx));
+            const R cc = fm(ocz, ocz, fm(ocy, ocy, fm(ocx, ocx, -q.r2)));
+            const R disc = fm(-a, cc, hb * hb);
+            if (disc >= R(0)) {
+                // narrow phase: the reference's quadratic (src/geom.zig:40-58) in f64 on the f64 sphere,
+                // for the ray as the kernel holds it; roots rounded to R before the range test
+                const double dx = d.x, dy = d.y, dz = d.z, tm = time;
+                double qx = q.c64[0] - (double)o.x, qy = q.c64[1] - (double)o.y, qz = q.c64[2] - (double)o.z;
+                if (i >= sc.n_static) {
+                    qx = std::fma(q.v64[0], tm, qx);
+                    qy = std::fma(q.v64[1], tm, qy);
+                    qz = std::fma(q.v64[2], tm, qz);
+                }
+                const double a2 = std::fma(dz, dz, std::fma(dy, dy, dx * dx));
+                const double hb2 = std::fma(dz, qz, std::fma(dy, qy, dx * qx));
+                const double cc2 = std::fma(qz, qz, std::fma(qy, qy, std::fma(qx, qx, -q.r2_64)));
+                const double disc2 = std::fma(-a2, cc2, hb2 * hb2);
+                if (disc2 >= 0.0) {
+                    const double rt = std::sqrt(disc2);
+                    const R t1 = (R)((hb2 - rt) / a2), t2 = (R)((hb2 + rt) / a2);
+                    if (t1 >= tmin && t1 <= tbest) {
+                        tbest = t1;
+                        ibest = (int)i;
+                    } else if (t2 >= tmin && t2 <= tbest) {
+                        tbest = t2;
+                        ibest = (int)i;
+                    }
+                }
+            }
+        }
+        if (ibest < 0) {                                                     // miss, src/renderer.zig:124-125
+            const V<R> u = unit(d);
+            const R t = R(0.5) * (u.y + R(1));
+            const R w = R(1) - t;
+            const V<R> col{(w + R(0.5)) * t, (w + R(0.7)) * t, (w + R(1.0)) * t};
+            res.L = {thr.x * col.x, thr.y * col.y, thr.z * col.z};
+            return res;
+        }
+        // --- hit record, src/geom.zig:63-65 + src/hit.zig:25-41 ---
+        const Sph<R>& q = sc.sph[ibest];
+        const V<R> pt{fm(d.x, tbest, o.x), fm(d.y, tbest, o.y), fm(d.z, tbest, o.z)};
+        const V<R> cn{fm(q.v.x, time, q.c.x), fm(q.v.y, time, q.c.y), fm(q.v.z, time, q.c.z)};
+        V<R> nrm = unit(V<R>{pt.x - cn.x, pt.y - cn.y, pt.z - cn.z});
+        const bool front = dot3(nrm, d) < R(0);
+        if (!front) nrm = neg(nrm);
+
+        const Mat<R>& m = sc.mats[q.mat];
+        V<R> nd, att;
+        if (m.kind == RAYZ_MAT_DIFFUSE) {                                    // src/material.zig:77-101
+            V<R> target;
+            if (m.method == RAYZ_DIFFUSE_HEMISPHERE) {
+                V<R> r = randomInUnitSphere(g);
+                if (!(dot3(r, nrm) > R(0))) r = neg(r);                      // :208-211
+                target = {pt.x + r.x, pt.y + r.y, pt.z + r.z};
+            } else {
+                V<R> r = randomInUnitSphere(g);
+                if (m.method == RAYZ_DIFFUSE_UNIT_SPHERE_SURFACE) r = unit(r);
+                target = {(pt.x + nrm.x) + r.x, (pt.y + nrm.y) + r.y, (pt.z + nrm.z) + r.z};
+            }
+            const R tol = (R)1e-8;
+            if (std::fabs(target.x) <= tol && std::fabs(target.y) <= tol && std::fabs(target.z) <= tol)
+                target = nrm;                                                // :85-86 (tests the POINT; preserved)
+            nd = {target.x - pt.x, target.y - pt.y, target.z - pt.z};
+            att = textureValue(sc, m.texture, pt);
+        } else if (m.kind == RAYZ_MAT_METALLIC) {                            // :108-131
+            const R k = R(2) * dot3(d, nrm);
+            V<R> r = unit(V<R>{fm(-k, nrm.x, d.x), fm(-k, nrm.y, d.y), fm(-k, nrm.z, d.z)});
+            if (m.param > R(0)) {
+                const V<R> ru = unit(randomInUnitSphere(g));
+                const R f = m.param < R(1) ? m.param : R(1);
+                r = {fm(ru.x, f, r.x), fm(ru.y, f, r.y), fm(ru.z, f, r.z)};
+            }
+            if (dot3(r, nrm) <= R(0)) return res;                            // absorbed → black
+            nd = r;
+            att = textureValue(sc, m.texture, pt);
+        } else {                                                             // :137-159
+            const R eta = front ? m.inv_param : m.param;
+            const V<R> ud = unit(d);
+            const R cosv = -dot3(ud, nrm);
+            const R sinv = std::sqrt(fm(-cosv, cosv, R(1)));
+            bool refl = eta * sinv > R(1);
+            if (!refl) {
+                R r0 = (R(1) - eta) / (R(1) + eta);                          // :179-183, pow(x,5) → x²·x²·x
+                r0 = r0 * r0;
+                const R xx = R(1) - cosv;
+                const R x2 = xx * xx;
+                const R x5 = (x2 * x2) * xx;
+                const R rf = fm(R(1) - r0, x5, r0);
+                refl = rf > g.uniform();
+            }
+            if (refl) {
+                const R k = R(2) * dot3(d, nrm);                             // :185-187, unnormalised d
+                nd = {fm(-k, nrm.x, d.x), fm(-k, nrm.y, d.y), fm(-k, nrm.z, d.z)};
+            } else {                                                         // :189-194
+                const V<R> perp{fm(nrm.x, cosv, ud.x) * eta, fm(nrm.y, cosv, ud.y) * eta,
+                                fm(nrm.z, cosv, ud.z) * eta};
+                const R sp = -std::sqrt(R(1) - dot3(perp, perp));
+                nd = {fm(nrm.x, sp, perp.x), fm(nrm.y, sp, perp.y), fm(nrm.z, sp, perp.z)};
+            }
+            att = {1, 1, 1};
+        }
+        thr = {thr.x * att.x, thr.y * att.y, thr.z * att.z};
+        o = pt;
+        d = nd;
+    }
+    return res; // depth exhausted → black, src/renderer.zig:104-105
+}
+
+static inline u32 shardRows(const RayzRenderParams& p, std::vector<u32>* rows) {
+    const u32 tr = p.tile_rows ? p.tile_rows : 8;
+    const u32 sc = p.shard_count ? p.shard_count : 1;
+    u32 n = 0;
+    for (u32 r = 0; r < p.height; ++r)
+        if ((r / tr) % sc == p.shard_index) {
+            if (rows) rows->push_back(r);
+            ++n;
+        }
+    return n;
+}
+
+template <class R>
+static int render(const RayzSceneDesc* sd, const RayzCameraDesc* cd, const RayzRenderParams* pp,
+                  const u32* pixel_list, u32 n_list, R* out, RayzRenderStats* stats, int threads) {
+    if (!sd || !cd || !pp || !out) return RAYZ_ERR_BAD_ARG;
+    const RayzRenderParams p = *pp;
+    if (!p.width || !p.height || !p.samples_per_px) return RAYZ_ERR_BAD_ARG;
+    const SceneB<R> sc = buildScene<R>(*sd);
+    const CamB<R> cam = buildCamera<R>(*cd);
+    const u32 C = p.chunk_spp ? p.chunk_spp : 16;
+    std::vector<u32> pixels; // global pixel indices, in output order
+    if (pixel_list) pixels.assign(pixel_list, pixel_list + n_list);
+    else {
+        std::vector<u32> rows;
+        shardRows(p, &rows);
+        for (u32 r : rows)
+            for (u32 i = 0; i < p.width; ++i) pixels.push_back(r * p.width + i);
+    }
+    u64 segs = 0;
+    const long np = (long)pixels.size();
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#pragma omp parallel for schedule(dynamic, 16) reduction(+ : segs)
+#endif
+    for (long k = 0; k < np; ++k) {
+        const u32 px = pixels[k] % p.width, py = pixels[k] / p.width;
+        V<R> pix{0, 0, 0};
+        for (u32 s0 = 0; s0 < p.samples_per_px; s0 += C) {
+            const u32 s1 = std::min(p.samples_per_px, s0 + C);
+            V<R> acc{0, 0, 0};
+            for (u32 s = s0; s < s1; ++s) {
+                const PathResult<R> r = tracePath<R>(sc, cam, p, px, py, s);
+                acc = {acc.x + r.L.x, acc.y + r.L.y, acc.z + r.L.z};
+                segs += r.segments;
+            }
+            pix = {pix.x + acc.x, pix.y + acc.y, pix.z + acc.z};
+        }
+        const R inv = R(1) / (R)p.samples_per_px;                            // acc.div(spp), src/renderer.zig:94-95
+        out[3 * k + 0] = pix.x * inv;
+        out[3 * k + 1] = pix.y * inv;
+        out[3 * k + 2] = pix.z * inv;
+    }
+    (void)threads;
+    if (stats) {
+        stats->primary_rays = (u64)np * p.samples_per_px;
+        stats->segments = segs;
+        stats->sphere_tests = segs * sd->n_spheres;
+        stats->node_tests = 0;
+        stats->kernel_ms = 0;
+    }
+    return RAYZ_OK;
+}
+
+} // namespace B
+
+static A::Scene sceneA(const RayzSceneDesc& d) {
+    A::Scene sc;
+    for (u32 i = 0; i < d.n_spheres; ++i) {
+        A::Sphere s;
+        s.center.origin = A::v3(d.spheres[i].center);
+        s.center.dir = A::v3(d.spheres[i].velocity);
+        s.radius = d.spheres[i].radius;
+        s.material = d.spheres[i].material;
+        sc.spheres.push_back(s);
+    }
+    sc.materials.assign(d.materials, d.materials + d.n_materials);
+    sc.textures.assign(d.textures, d.textures + d.n_textures);
+    for (u32 i = 0; i < d.n_spheres; ++i)                                    // src/ecs.zig:43-51
+        sc.hittables.push_back({sc.spheres[i].boundingBox(), i});
+    return sc;
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------------
+// C entry points (loaded with ctypes by tests/ and bench.py only)
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+// ---- mode B ----
+int rayz_oracle_render_b_f32(const RayzSceneDesc* s, const RayzCameraDesc* c, const RayzRenderParams* p,
+                             const uint32_t* pixel_list, uint32_t n_list, float* out, RayzRenderStats* st,
+                             int threads) {
+    return B::render<float>(s, c, p, pixel_list, n_list, out, st, threads);
+}
+int rayz_oracle_render_b_f64(const RayzSceneDesc* s, const RayzCameraDesc* c, const RayzRenderParams* p,
+                             const uint32_t* pixel_list, uint32_t n_list, double* out, RayzRenderStats* st,
+                             int threads) {
+    return B::render<double>(s, c, p, pixel_list, n_list, out, st, threads);
+}
+uint32_t rayz_oracle_shard_rows(const RayzRenderParams* p) { return B::shardRows(*p, nullptr); }
+
+// ---- mode A: `Tracer.render` over rows [row_begin,row_end) with ONE sequential stream ----
+// rng_state: 4 u64 in/out (the Tracer's DefaultPrng, continued from scene generation, src/rayz.zig:109).
+// out: (row_end-row_begin)*width*3 doubles; sumsq (optional) receives per-pixel Σ L² per channel.
+int rayz_oracle_render_a(const RayzSceneDesc* sd, const RayzCameraDesc* cd, const RayzRenderParams* pp,
+                         uint32_t row_begin, uint32_t row_end, uint64_t* rng_state, int linear, double* out,
+                         double* sumsq, RayzRenderStats* stats) {
+    if (!sd || !cd || !pp || !out || !rng_state || row_end > pp->height || row_begin > row_end)
+        return RAYZ_ERR_BAD_ARG;
+    A::Tracer t;
+    t.sc = sceneA(*sd);
+    t.cam = A::cameraFrom(*cd);
+    std::memcpy(t.rng.s, rng_state, 32);
+    t.tmin = pp->tmin;
+    t.linear = linear != 0;
+    if (!t.linear && !t.sc.hittables.empty()) t.bvh.build(t.sc.hittables, 0, t.sc.hittables.size()); // src/renderer.zig:76-78
+    u64 rays = 0;
+    for (u32 j = row_begin; j < row_end; ++j) {                              // src/renderer.zig:80-97
+        for (u32 i = 0; i < pp->width; ++i) {
+            A::V3 acc, sq;
+            for (u32 r = 0; r < pp->samples_per_px; ++r) {
+                const A::Ray ray = t.cam.getRay(i, j, &t.rng);
+                rays++;
+                const A::V3 L = t.bounceRay(ray, pp->max_bounces);
+                acc = acc.add(L);
+                sq = sq.add(L.vmul(L));
+            }
+            const A::V3 px = acc.div((double)pp->samples_per_px);
+            const size_t k = ((size_t)(j - row_begin) * pp->width + i) * 3;
+            out[k] = px.x;
+            out[k + 1] = px.y;
+            out[k + 2] = px.z;
+            if (sumsq) {
+                sumsq[k] = sq.x;
+                sumsq[k + 1] = sq.y;
+                sumsq[k + 2] = sq.z;
+            }
+        }
+    }
+    std::memcpy(rng_state, t.rng.s, 32);
+    if (stats) {
+        stats->primary_rays = rays;
+        stats->segments = t.cnt.segments;
+        stats->sphere_tests = t.cnt.sphere_tests;
+        stats->node_tests = t.cnt.node_tests;
+        stats->kernel_ms = 0;
+    }
+    return RAYZ_OK;
+}
+
+// ---- pieces the reference's own tests pin ----
+void rayz_oracle_camera_init(double vfov, double focus_dist, double defocus_angle, const double* look_from,
+                             const double* look_at, const double* vup, uint32_t img_h, uint32_t img_w,
+                             RayzCameraDesc* out) {
+    A::cameraTo(A::Camera::init(vfov, focus_dist, defocus_angle, A::v3(look_from), A::v3(look_at), A::v3(vup), img_h,
+                                img_w),
+                out);
+}
+void rayz_oracle_get_ray_norng(const RayzCameraDesc* c, uint32_t px, uint32_t py, double* origin, double* dir) {
+    const A::Ray r = A::cameraFrom(*c).getRay(px, py, nullptr);
+    origin[0] = r.origin.x, origin[1] = r.origin.y, origin[2] = r.origin.z;
+    dir[0] = r.dir.x, dir[1] = r.dir.y, dir[2] = r.dir.z;
+}
+void rayz_oracle_refract(const double* unit_dir, const double* n, double eta, double* out) {
+    const A::V3 r = A::refract(A::v3(unit_dir), A::v3(n), eta);
+    out[0] = r.x, out[1] = r.y, out[2] = r.z;
+}
+double rayz_oracle_reflectance(double cos, double ri) { return A::reflectance(cos, ri); }
+void rayz_oracle_sphere_bbox(const RayzSphere* s, double* low, double* high) {
+    A::Sphere q;
+    q.center.origin = A::v3(s->center);
+    q.center.dir = A::v3(s->velocity);
+    q.radius = s->radius;
+    q.material = s->material;
+    const A::AABB b = q.boundingBox();
+    low[0] = b.low.x, low[1] = b.low.y, low[2] = b.low.z;
+    high[0] = b.high.x, high[1] = b.high.y, high[2] = b.high.z;
+}
+void rayz_oracle_aabb_enclose(const double* alo, const double* ahi, const double* blo, const double* bhi, double* lo,
+                              double* hi) {
+    const A::AABB r = A::AABB::enclose(A::AABB::init(A::v3(alo), A::v3(ahi)), A::AABB::init(A::v3(blo), A::v3(bhi)));
+    lo[0] = r.low.x, lo[1] = r.low.y, lo[2] = r.low.z;
+    hi[0] = r.high.x, hi[1] = r.high.y, hi[2] = r.high.z;
+}
+int rayz_oracle_aabb_hit(const double* a, const double* b, const double* origin, const double* dir, double tmin,
+                         double tmax) {
+    A::Ray r;
+    r.origin = A::v3(origin);
+    r.dir = A::v3(dir);
+    return A::AABB::init(A::v3(a), A::v3(b)).hit(r, tmin, tmax) ? 1 : 0;
+}
+// op: 0 add, 1 sub, 2 mul(b[0]), 3 unit, 4 cross, 5 vmul, 6 sqrt, 7 clamp(b[0],b[1]), 8 div(b[0])
+void rayz_oracle_v3_op(int op, const double* a, const double* b, double* out) {
+    const A::V3 x = A::v3(a), y = b ? A::v3(b) : A::V3{};
+    A::V3 r;
+    switch (op) {
+    case 0: r = x.add(y); break;
+    case 1: r = x.sub(y); break;
+    case 2: r = x.mul(y.x); break;
+    case 3: r = x.unit(); break;
+    case 4: r = x.cross(y); break;
+    case 5: r = x.vmul(y); break;
+    case 6: r = x.sqrt(); break;
+    case 7: r = x.clamp(y.x, y.y); break;
+    case 8: r = x.div(y.x); break;
+    default: break;
+    }
+    out[0] = r.x, out[1] = r.y, out[2] = r.z;
+}
+double rayz_oracle_v3_dot(const double* a, const double* b) { return A::v3(a).dot(A::v3(b)); }
+double rayz_oracle_v3_mag(const double* a) { return A::v3(a).mag(); }
+int rayz_oracle_v3_amax(const double* a) { return A::v3(a).amax(); }
+
+// `Image.writePPM`'s per-pixel transform, src/image.zig:35-38
+void rayz_oracle_ppm_u8(const double* rgb, uint8_t* out) {
+    const A::V3 c = A::v3(rgb).sqrt().clamp(0, 1);
+    out[0] = (uint8_t)(c.x * 255);
+    out[1] = (uint8_t)(c.y * 255);
+    out[2] = (uint8_t)(c.z * 255);
+}
+// whole file, src/image.zig:29-41
+int rayz_oracle_write_ppm(const char* path, const double* rgb, uint32_t w, uint32_t h) {
+    FILE* f = std::fopen(path, "w");
+    if (!f) return -1;
+    std::fprintf(f, "P3\n%u %u\n%d\n", w, h, 255);
+    for (size_t i = 0; i < (size_t)w * h; ++i) {
+        uint8_t c[3];
+        rayz_oracle_ppm_u8(rgb + 3 * i, c);
+        std::fprintf(f, "%u %u %u\n", c[0], c[1], c[2]);
+    }
+    std::fclose(f);
+    return 0;
+}
+
+// ---- RNG streams ----
+void rayz_oracle_splitmix64(uint64_t seed, uint32_t n, uint64_t* out) {
+    SplitMix64 g{seed};
+    for (u32 i = 0; i < n; ++i) out[i] = g.next();
+}
+void rayz_oracle_xoshiro_seed(uint64_t seed, uint64_t* state) {
+    Xoshiro256pp g;
+    g.seed(seed);
+    std::memcpy(state, g.s, 32);
+}
+void rayz_oracle_xoshiro_u64(uint64_t* state, uint32_t n, uint64_t* out) {
+    Xoshiro256pp g;
+    std::memcpy(g.s, state, 32);
+    for (u32 i = 0; i < n; ++i) out[i] = g.next();
+    std::memcpy(state, g.s, 32);
+}
+void rayz_oracle_xoshiro_f64(uint64_t* state, uint32_t n, double* out) {
+    Xoshiro256pp g;
+    std::memcpy(g.s, state, 32);
+    for (u32 i = 0; i < n; ++i) out[i] = g.float64();
+    std::memcpy(state, g.s, 32);
+}
+void rayz_oracle_pcg32(uint64_t initstate, uint64_t initseq, uint32_t n, uint32_t* out) {
+    Pcg32 g;
+    g.srandom(initstate, initseq);
+    for (u32 i = 0; i < n; ++i) out[i] = g.next();
+}
+void rayz_oracle_pcg32_path(uint64_t seed, uint64_t path_id, uint32_t n, uint32_t* out) {
+    Pcg32 g;
+    g.seed_path(seed, path_id);
+    for (u32 i = 0; i < n; ++i) out[i] = g.next();
+}
+
+// ---- scene `randomBouncing`, src/rayz.zig:45-168, grid a,b ∈ [lo,hi) (reference: -11, 11) ----
+// Draws from the Tracer's stream (rng_state in/out, src/rayz.zig:109).  counts = {spheres, materials, textures}.
+int rayz_oracle_random_bouncing(uint64_t* rng_state, int lo, int hi, RayzSphere* sph, uint32_t cap_s,
+                                RayzMaterial* mat, uint32_t cap_m, RayzTexture* tex, uint32_t cap_t,
+                                uint32_t* counts) {
+    Xoshiro256pp g;
+    std::memcpy(g.s, rng_state, 32);
+    u32 ns = 0, nm = 0, nt = 0;
+    auto addTex = [&](u32 kind, double scale, u32 even, u32 odd, double r, double gg, double b) -> int {
+        if (nt >= cap_t) return -1;
+        RayzTexture t{};
+        t.kind = kind, t.even = even, t.odd = odd, t.scale = scale;
+        t.color[0] = r, t.color[1] = gg, t.color[2] = b;
+        tex[nt] = t;
+        return (int)nt++;
+    };
+    auto addMat = [&](u32 kind, u32 texture, double param) -> int {
+        if (nm >= cap_m) return -1;
+        RayzMaterial m{};
+        m.kind = kind, m.texture = texture, m.method = RAYZ_DIFFUSE_HEMISPHERE, m.param = param;
+        mat[nm] = m;
+        return (int)nm++;
+    };
+    auto addSph = [&](double cx, double cy, double cz, double vy, double r, u32 m) -> int {
+        if (ns >= cap_s) return -1;
+        RayzSphere s{};
+        s.center[0] = cx, s.center[1] = cy, s.center[2] = cz;
+        s.velocity[1] = vy;
+        s.radius = r, s.material = m;
+        sph[ns] = s;
+        return (int)ns++;
+    };
+    // ground: Zig evaluates the nested `try` arguments innermost-first: even, odd, checker, material, sphere
+    int e = addTex(RAYZ_TEX_SOLID, 0, 0, 0, 0.2, 0.3, 0.1);                  // :64-68
+    int o = addTex(RAYZ_TEX_SOLID, 0, 0, 0, 0.9, 0.9, 0.9);                  // :69-71
+    if (e < 0 || o < 0) return -1;
+    int ck = addTex(RAYZ_TEX_CHECKER, 0.32, (u32)e, (u32)o, 0, 0, 0);        // :62-72
+    if (ck < 0) return -1;
+    int m = addMat(RAYZ_MAT_DIFFUSE, (u32)ck, 0);
+    if (m < 0 || addSph(0, -1000, 0, 0, 1000, (u32)m) < 0) return -1;        // :58-74
+    m = addMat(RAYZ_MAT_DIELECTRIC, 0, 1.5);                                 // :77-83
+    if (m < 0 || addSph(0, 1, 0, 0, 1.0, (u32)m) < 0) return -1;
+    int t = addTex(RAYZ_TEX_SOLID, 0, 0, 0, 0.4, 0.2, 0.1);                  // :84-92
+    if (t < 0) return -1;
+    m = addMat(RAYZ_MAT_DIFFUSE, (u32)t, 0);
+    if (m < 0 || addSph(-4, 1, 0, 0, 1.0, (u32)m) < 0) return -1;
+    t = addTex(RAYZ_TEX_SOLID, 0, 0, 0, 0.7, 0.6, 0.5);                      // :93-106
+    if (t < 0) return -1;
+    m = addMat(RAYZ_MAT_METALLIC, (u32)t, 0);
+    if (m < 0 || addSph(4, 1, 0, 0, 1.0, (u32)m) < 0) return -1;
+    for (int a = lo; a < hi; ++a) {                                          // :110-166
+        for (int b = lo; b < hi; ++b) {
+            const double rand_mat = g.float64();
+            A::V3 center{(double)a + 0.9 * g.float64(), 0.2, (double)b + 0.9 * g.float64()};
+            if (center.sub(A::V3{4, 0.2, 0}).mag() <= 0.9) continue;
+            double vy = 0;
+            int mh;
+            if (rand_mat < 0.8) {
+                const A::V3 c1 = A::v3random(g, 0, 1.0);
+                const A::V3 c2 = A::v3random(g, 0, 1.0);
+                const A::V3 col = c1.vmul(c2);
+                t = addTex(RAYZ_TEX_SOLID, 0, 0, 0, col.x, col.y, col.z);
+                if (t < 0) return -1;
+                mh = addMat(RAYZ_MAT_DIFFUSE, (u32)t, 0);
+                vy = A::V3{0, 1, 0}.mul(g.float64() * 0.5).y;
+            } else if (rand_mat < 0.95) {
+                const double fuzz = g.float64() * 0.5;                       // field order: fuzz, then texture
+                const A::V3 col = A::v3random(g, 0.5, 1.0);
+                t = addTex(RAYZ_TEX_SOLID, 0, 0, 0, col.x, col.y, col.z);
+                if (t < 0) return -1;
+                mh = addMat(RAYZ_MAT_METALLIC, (u32)t, fuzz);
+            } else {
+                mh = addMat(RAYZ_MAT_DIELECTRIC, 0, 1.5);
+            }
+            if (mh < 0 || addSph(center.x, center.y, center.z, vy, 0.2, (u32)mh) < 0) return -1;
+        }
+    }
+    std::memcpy(rng_state, g.s, 32);
+    counts[0] = ns, counts[1] = nm, counts[2] = nt;
+    return RAYZ_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,484 @@
+// rayz_device.hpp — gfx950 device code of the render path (included by rayz_hip.hip only).
+//
+// One work-item per pixel-sample path.  A wave keeps 64 paths in flight and re-fills finished lanes
+// from a global work queue (wave64 ballot + mbcnt prefix ranks, one atomic per wave), so the sphere
+// scan — ≥95 % of the time on a flat hit list — always runs with a full EXEC mask.  The scan is
+// wave-uniform over the sphere index: sphere records come through the SCALAR path (s_load_dwordx4/x8
+// from a constant-address-space pointer) and feed the VALU as SGPR operands, which costs no VGPRs, no
+// LDS bandwidth and no 64× replicated vector loads.  Arithmetic is the "mode B" specification of
+// DESIGN.md §4; every statement below has its twin in oracle/rayz_oracle.cpp namespace B, and the two
+// must agree bit for bit (build with -ffp-contract=off: FMAs appear only where written).
+//
+// Reference semantics restated here (file:line into jlucier/rayz):
+//   camera ray      src/camera.zig:59-90      sphere test   src/geom.zig:38-66
+//   hit record      src/hit.zig:25-41         scatter       src/material.zig:73-160,179-211
+//   textures        src/material.zig:19-51    bounce loop   src/renderer.zig:103-126 (recursion → loop)
+//   pixel mean      src/renderer.zig:86-95
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rayz_dev {
+
+#define RAYZ_CONSTANT __attribute__((address_space(4)))
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+
+constexpr int kMaxRejectionTries = 64;
+constexpr int kMaxTextureDepth = 8;
+constexpr int kStaticUnroll = 4; // static spheres per scan group (records padded to a multiple)
+constexpr int kMovingUnroll = 4; // moving spheres per scan group
+
+template <class R> struct VecOf;
+template <> struct VecOf<float> { typedef f4 type; };
+template <> struct VecOf<double> { typedef d4 type; };
+
+// ---- device-resident scene (HBM layout) ------------------------------------------
+template <class R> struct DevScene {
+    typedef typename VecOf<R>::type r4;
+    const r4* stat;      // [ns_pad]      {cx, cy, cz, r²}; pad records have r² = -inf (never hit)
+    const r4* mov;       // [2 * nm_pad]  {cx, cy, cz, r²}, {vx, vy, vz, 0}
+    const d4* stat64;    // the same records as the pool holds them (f64): narrow phase.  For R = double
+    const d4* mov64;     //   these alias stat / mov.
+    const uint32_t* sphere_mat; // [ns_pad + nm_pad] material index in device order
+    const r4* mat;       // [n_mat] {bits(kind | method << 8), bits(texture), param, 1/param}
+    const r4* tex;       // [2 * n_tex] {bits(kind), bits(even), bits(odd), scale}, {r, g, b, 0}
+    uint32_t ns_pad, nm_pad, n_spheres, _pad;
+};
+
+template <class R> struct DevCamera {
+    R from[3], du[3], dv[3], pxo[3], defu[3], defv[3];
+    uint32_t defocus, _pad;
+};
+
+template <class R> struct TraceArgs {
+    DevScene<R> sc;
+    DevCamera<R> cam;
+    typename VecOf<R>::type* partial; // [total_items] chunk sums
+    unsigned long long* counters;     // [0] work-queue head, [1] segments
+    unsigned long long seed;
+    R tmin;
+    uint32_t width, height, spp, max_bounces;
+    uint32_t chunk_spp, chunks_per_px;
+    uint32_t tile_rows, shard_index, shard_count, shard_pixels;
+    uint32_t total_items, _pad;
+};
+
+// ---- small helpers -----------------------------------------------------------------------------
+__device__ __forceinline__ float fm(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fm(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float mx(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ double mx(double a, double b) { return __builtin_fmax(a, b); }
+__device__ __forceinline__ float sq(float x) { return __builtin_sqrtf(x); }
+__device__ __forceinline__ double sq(double x) { return __builtin_sqrt(x); }
+__device__ __forceinline__ float fl(float x) { return __builtin_floorf(x); }
+__device__ __forceinline__ double fl(double x) { return __builtin_floor(x); }
+__device__ __forceinline__ float ab(float x) { return __builtin_fabsf(x); }
+__device__ __forceinline__ double ab(double x) { return __builtin_fabs(x); }
+__device__ __forceinline__ uint32_t bits(float x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ uint32_t bits(double x) { return (uint32_t)__builtin_bit_cast(uint64_t, x); }
+
+template <class R> struct V {
+    R x, y, z;
+};
+template <class R> __device__ __forceinline__ R dot3(V<R> a, V<R> b) { return fm(a.z, b.z, fm(a.y, b.y, a.x * b.x)); }
+template <class R> __device__ __forceinline__ V<R> neg(V<R> a) { return {-a.x, -a.y, -a.z}; }
+template <class R> __device__ __forceinline__ V<R> unit(V<R> a) {
+    const R m = sq(dot3(a, a));
+    const R inv = R(1) / m;
+    return {a.x * inv, a.y * inv, a.z * inv};
+}
+
+// ---- PCG32 (XSH-RR 64/32), one stream per path: DESIGN.md §4.1 ---------------------------------
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+struct Pcg32 {
+    unsigned long long state, inc;
+    __device__ __forceinline__ uint32_t next() {
+        const unsigned long long old = state;
+        state = old * 6364136223846793005ull + inc;
+        const uint32_t xorshifted = (uint32_t)(((old >> 18u) ^ old) >> 27u);
+        const uint32_t rot = (uint32_t)(old >> 59u);
+        return (xorshifted >> rot) | (xorshifted << ((32u - rot) & 31u));
+    }
+    __device__ __forceinline__ void seed_path(unsigned long long seed, unsigned long long path_id) {
+        const unsigned long long a = mix64(seed + (path_id + 1) * 0x9e3779b97f4a7c15ull);
+        const unsigned long long b = mix64(a + 0x9e3779b97f4a7c15ull);
+        state = 0;
+        inc = (b << 1) | 1u;
+        next();
+        state += a;
+        next();
+    }
+};
+template <class R> __device__ __forceinline__ R uniform(Pcg32& g);
+template <> __device__ __forceinline__ float uniform<float>(Pcg32& g) { return (float)(g.next() >> 8) * 0x1p-24f; }
+template <> __device__ __forceinline__ double uniform<double>(Pcg32& g) { return (double)g.next() * 0x1p-32; }
+
+template <class R> __device__ __forceinline__ V<R> random_in_unit_sphere(Pcg32& g) { // src/material.zig:196-202
+    V<R> v{0, 0, 0};
+    for (int i = 0; i < kMaxRejectionTries; ++i) {
+        v.x = fm(uniform<R>(g), R(2), R(-1));
+        v.y = fm(uniform<R>(g), R(2), R(-1));
+        v.z = fm(uniform<R>(g), R(2), R(-1));
+        if (sq(dot3(v, v)) <= R(1)) break;
+    }
+    return v;
+}
+
+template <class R>
+__device__ __forceinline__ V<R> texture_value(const DevScene<R>& sc, uint32_t idx, V<R> p) { // src/material.zig:19-51
+    typedef typename VecOf<R>::type r4;
+    for (int depth = 0; depth < kMaxTextureDepth; ++depth) {
+        const r4 h = sc.tex[2 * idx];
+        if (bits(h.x) == 1u) { // RAYZ_TEX_SOLID
+            const r4 c = sc.tex[2 * idx + 1];
+            return {c.x, c.y, c.z};
+        }
+        const R scale = h.w;
+        const R lim = R(1073741824.0);
+        R fx = fl(p.x / scale), fy = fl(p.y / scale), fz = fl(p.z / scale);
+        fx = fx < -lim ? -lim : fx;
+        fx = fx > lim ? lim : fx;
+        fy = fy < -lim ? -lim : fy;
+        fy = fy > lim ? lim : fy;
+        fz = fz < -lim ? -lim : fz;
+        fz = fz > lim ? lim : fz;
+        const uint32_t s = (uint32_t)(int32_t)fx + (uint32_t)(int32_t)fy + (uint32_t)(int32_t)fz;
+        idx = (s & 1u) == 0u ? bits(h.y) : bits(h.z);
+    }
+    return {R(0), R(0), R(0)};
+}
+
+// ---- narrow phase: one candidate that passed the reject test, src/geom.zig:40-61 ------------------
+// The reference's quadratic in f64 on the pool's f64 sphere, for the ray as the kernel holds it; the
+// roots are rounded to R before the inclusive range test.  `rec` is wave-uniform (scalar loads).
+template <class R, bool MOVING>
+__device__ __forceinline__ void narrow_phase(const RAYZ_CONSTANT d4* rec, R disc_fast, V<R> o, V<R> d, R time, R tmin,
+                                             int idx, R& tbest, int& ibest) {
+    if (disc_fast >= R(0)) {
+        const d4 c = rec[0];
+        const double dx = d.x, dy = d.y, dz = d.z;
+        double qx = c.x - (double)o.x, qy = c.y - (double)o.y, qz = c.z - (double)o.z;
+        if (MOVING) {
+            const d4 v = rec[1];
+            const double tm = time;
+            qx = fm(v.x, tm, qx);
+            qy = fm(v.y, tm, qy);
+            qz = fm(v.z, tm, qz);
+        }
+        const double a2 = fm(dz, dz, fm(dy, dy, dx * dx));
+        const double hb2 = fm(dz, qz, fm(dy, qy, dx * qx));
+        const double cc2 = fm(qz, qz, fm(qy, qy, fm(qx, qx, -c.w)));
+        const double disc2 = fm(-a2, cc2, hb2 * hb2);
+        if (disc2 >= 0.0) {
+            const double rt = __builtin_sqrt(disc2);
+            const R t1 = (R)((hb2 - rt) / a2), t2 = (R)((hb2 + rt) / a2);
+            if (t1 >= tmin && t1 <= tbest) {
+                tbest = t1;
+                ibest = idx;
+            } else if (t2 >= tmin && t2 <= tbest) {
+                tbest = t2;
+                ibest = idx;
+            }
+        }
+    }
+}
+
+// ---- the flat-list scan: nearest hit of ray (o, d, time) over every sphere ---------------------
+// Wave-uniform in the sphere index.  Reject test in R — per static sphere 3 sub + (mul,fma,fma) + 3 fma +
+// (mul,fma) = 11 VALU, per moving sphere +3 fma = 14, plus (3 max + 1 cmp)/4 for the group reject — and
+// narrow_phase() for the few candidates whose line meets the sphere.
+template <class R>
+__device__ __forceinline__ void scan_spheres(const DevScene<R>& sc, V<R> o, V<R> d, R time, R tmin, R& tbest,
+                                             int& ibest) {
+    typedef typename VecOf<R>::type r4;
+    const RAYZ_CONSTANT r4* stat = (const RAYZ_CONSTANT r4*)sc.stat;
+    const RAYZ_CONSTANT r4* mov = (const RAYZ_CONSTANT r4*)sc.mov;
+    const RAYZ_CONSTANT d4* stat64 = (const RAYZ_CONSTANT d4*)sc.stat64;
+    const RAYZ_CONSTANT d4* mov64 = (const RAYZ_CONSTANT d4*)sc.mov64;
+    const R a = dot3(d, d);
+    tbest = (R)__builtin_inff();
+    ibest = -1;
+    const int ns = (int)sc.ns_pad, nm = (int)sc.nm_pad;
+    for (int i = 0; i < ns; i += kStaticUnroll) {
+        R disc[kStaticUnroll];
+#pragma unroll
+        for (int k = 0; k < kStaticUnroll; ++k) {
+            const r4 c = stat[i + k];
+            const R ocx = c.x - o.x, ocy = c.y - o.y, ocz = c.z - o.z;
+            const R hb = fm(d.z, ocz, fm(d.y, ocy, d.x * ocx));
+            const R cc = fm(ocz, ocz, fm(ocy, ocy, fm(ocx, ocx, -c.w)));
+            disc[k] = fm(-a, cc, hb * hb);
+        }
+        R m = disc[0];
+#pragma unroll
+        for (int k = 1; k < kStaticUnroll; ++k) m = mx(m, disc[k]);
+        if (m >= R(0)) {
+#pragma unroll
+            for (int k = 0; k < kStaticUnroll; ++k)
+                narrow_phase<R, false>(stat64 + (i + k), disc[k], o, d, time, tmin, i + k, tbest, ibest);
+        }
+    }
+    for (int i = 0; i < nm; i += kMovingUnroll) {
+        R disc[kMovingUnroll];
+#pragma unroll
+        for (int k = 0; k < kMovingUnroll; ++k) {
+            const r4 c = mov[2 * (i + k)], v = mov[2 * (i + k) + 1];
+            R ocx = c.x - o.x, ocy = c.y - o.y, ocz = c.z - o.z;
+            ocx = fm(v.x, time, ocx);
+            ocy = fm(v.y, time, ocy);
+            ocz = fm(v.z, time, ocz);
+            const R hb = fm(d.z, ocz, fm(d.y, ocy, d.x * ocx));
+            const R cc = fm(ocz, ocz, fm(ocy, ocy, fm(ocx, ocx, -c.w)));
+            disc[k] = fm(-a, cc, hb * hb);
+        }
+        R m = disc[0];
+#pragma unroll
+        for (int k = 1; k < kMovingUnroll; ++k) m = mx(m, disc[k]);
+        if (m >= R(0)) {
+#pragma unroll
+            for (int k = 0; k < kMovingUnroll; ++k)
+                narrow_phase<R, true>(mov64 + 2 * (i + k), disc[k], o, d, time, tmin, ns + i + k, tbest, ibest);
+        }
+    }
+}
+
+// ---- shading of one segment: returns false when the path ends ------------------------------------
+// On a miss adds thr ⊙ background to acc (src/renderer.zig:124-125); on absorption adds nothing.
+template <class R>
+__device__ __forceinline__ bool shade(const DevScene<R>& sc, Pcg32& g, V<R>& o, V<R>& d, R time, R tbest, int ibest,
+                                      V<R>& thr, V<R>& acc) {
+    typedef typename VecOf<R>::type r4;
+    if (ibest < 0) {
+        const V<R> u = unit(d);
+        const R t = R(0.5) * (u.y + R(1));
+        const R w = R(1) - t;
+        const V<R> col{(w + R(0.5)) * t, (w + R(0.7)) * t, (w + R(1.0)) * t};
+        acc.x = acc.x + thr.x * col.x;
+        acc.y = acc.y + thr.y * col.y;
+        acc.z = acc.z + thr.z * col.z;
+        return false;
+    }
+    // hit record: src/geom.zig:63-65, src/hit.zig:25-41
+    V<R> c, v;
+    if (ibest < (int)sc.ns_pad) {
+        const r4 q = sc.stat[ibest];
+        c = {q.x, q.y, q.z};
+        v = {R(0), R(0), R(0)};
+    } else {
+        const int j = ibest - (int)sc.ns_pad;
+        const r4 q = sc.mov[2 * j], w = sc.mov[2 * j + 1];
+        c = {q.x, q.y, q.z};
+        v = {w.x, w.y, w.z};
+    }
+    const V<R> pt{fm(d.x, tbest, o.x), fm(d.y, tbest, o.y), fm(d.z, tbest, o.z)};
+    const V<R> cn{fm(v.x, time, c.x), fm(v.y, time, c.y), fm(v.z, time, c.z)};
+    V<R> nrm = unit(V<R>{pt.x - cn.x, pt.y - cn.y, pt.z - cn.z});
+    const bool front = dot3(nrm, d) < R(0);
+    if (!front) nrm = neg(nrm);
+
+    const r4 m = sc.mat[sc.sphere_mat[ibest]];
+    const uint32_t kind = bits(m.x) & 0xffu, method = (bits(m.x) >> 8) & 0xffu, texture = bits(m.y);
+    const R param = m.z, inv_param = m.w;
+    V<R> nd, att;
+    if (kind == 0u) { // diffuse, src/material.zig:77-101
+        V<R> target;
+        V<R> r = random_in_unit_sphere<R>(g);
+        if (method == 2u) { // HEMISPHERE, :208-211
+            if (!(dot3(r, nrm) > R(0))) r = neg(r);
+            target = {pt.x + r.x, pt.y + r.y, pt.z + r.z};
+        } else {
+            if (method == 1u) r = unit(r); // UNIT_SPHERE_SURFACE
+            target = {(pt.x + nrm.x) + r.x, (pt.y + nrm.y) + r.y, (pt.z + nrm.z) + r.z};
+        }
+        const R tol = (R)1e-8;
+        if (ab(target.x) <= tol && ab(target.y) <= tol && ab(target.z) <= tol) target = nrm; // :85-86
+        nd = {target.x - pt.x, target.y - pt.y, target.z - pt.z};
+        att = texture_value<R>(sc, texture, pt);
+    } else if (kind == 1u) { // metallic, :108-131
+        const R k = R(2) * dot3(d, nrm);
+        V<R> r = unit(V<R>{fm(-k, nrm.x, d.x), fm(-k, nrm.y, d.y), fm(-k, nrm.z, d.z)});
+        if (param > R(0)) {
+            const V<R> ru = unit(random_in_unit_sphere<R>(g));
+            const R f = param < R(1) ? param : R(1);
+            r = {fm(ru.x, f, r.x), fm(ru.y, f, r.y), fm(ru.z, f, r.z)};
+        }
+        if (dot3(r, nrm) <= R(0)) return false; // absorbed
+        nd = r;
+        att = texture_value<R>(sc, texture, pt);
+    } else { // dielectric, :137-159
+        const R eta = front ? inv_param : param;
+        const V<R> ud = unit(d);
+        const R cosv = -dot3(ud, nrm);
+        const R sinv = sq(fm(-cosv, cosv, R(1)));
+        bool refl = eta * sinv > R(1);
+        if (!refl) { // the draw happens only when not totally internally reflecting, :145
+            R r0 = (R(1) - eta) / (R(1) + eta);
+            r0 = r0 * r0;
+            const R xx = R(1) - cosv;
+            const R x2 = xx * xx;
+            const R x5 = (x2 * x2) * xx;
+            const R rf = fm(R(1) - r0, x5, r0);
+            refl = rf > uniform<R>(g);
+        }
+        if (refl) {
+            const R k = R(2) * dot3(d, nrm);
+            nd = {fm(-k, nrm.x, d.x), fm(-k, nrm.y, d.y), fm(-k, nrm.z, d.z)};
+        } else {
+            const V<R> perp{fm(nrm.x, cosv, ud.x) * eta, fm(nrm.y, cosv, ud.y) * eta, fm(nrm.z, cosv, ud.z) * eta};
+            const R sp = -sq(R(1) - dot3(perp, perp));
+            nd = {fm(nrm.x, sp, perp.x), fm(nrm.y, sp, perp.y), fm(nrm.z, sp, perp.z)};
+        }
+        att = {R(1), R(1), R(1)};
+    }
+    thr = {thr.x * att.x, thr.y * att.y, thr.z * att.z};
+    o = pt;
+    d = nd;
+    return true;
+}
+
+// ---- camera ray of path (px, py, s): src/camera.zig:59-90 ---------------------------------------
+template <class R>
+__device__ __forceinline__ void camera_ray(const DevCamera<R>& cam, Pcg32& g, uint32_t px, uint32_t py, V<R>& o, V<R>& d,
+                                           R& time) {
+    const R x = (R)px + (uniform<R>(g) - R(0.5));
+    const R y = (R)py + (uniform<R>(g) - R(0.5));
+    o = {cam.from[0], cam.from[1], cam.from[2]};
+    if (cam.defocus) {
+        R vx = 0, vy = 0;
+        for (int i = 0; i < kMaxRejectionTries; ++i) {
+            vx = fm(uniform<R>(g), R(2), R(-1));
+            vy = fm(uniform<R>(g), R(2), R(-1));
+            if (fm(vy, vy, vx * vx) <= R(1)) break;
+        }
+        o.x = cam.from[0] + fm(cam.defv[0], vy, cam.defu[0] * vx);
+        o.y = cam.from[1] + fm(cam.defv[1], vy, cam.defu[1] * vx);
+        o.z = cam.from[2] + fm(cam.defv[2], vy, cam.defu[2] * vx);
+    }
+    d.x = (fm(cam.dv[0], y, cam.du[0] * x) + cam.pxo[0]) - o.x;
+    d.y = (fm(cam.dv[1], y, cam.du[1] * x) + cam.pxo[1]) - o.y;
+    d.z = (fm(cam.dv[2], y, cam.du[2] * x) + cam.pxo[2]) - o.z;
+    time = uniform<R>(g);
+}
+
+// ---- the persistent trace kernel ---------------------------------------------------------------
+// Work item = (pixel of this shard, chunk of ≤chunk_spp consecutive samples).  Items are numbered
+// chunk-major so that the 64 lanes of a wave start on 64 neighbouring pixels.  Each lane owns one
+// item at a time, runs its paths one after the other, adds their radiance in sample order, and
+// stores the chunk sum to partial[item]; resolve_kernel adds the chunk sums of a pixel in chunk
+// order.  The summation tree is therefore fixed by (spp, chunk_spp) alone — not by the schedule, the
+// grid size or the number of GPUs.
+template <class R> __global__ __launch_bounds__(256) void trace_kernel(const TraceArgs<R> A) {
+    typedef typename VecOf<R>::type r4;
+    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    Pcg32 g{0, 1};
+    V<R> o{0, 0, 0}, d{0, 0, 1}, thr{1, 1, 1}, acc{0, 0, 0};
+    R time = 0;
+    uint32_t item = 0, px = 0, py = 0, s_cur = 0, s_end = 0, seg = 0, nseg = 0;
+    bool has_item = false, alive = false;
+    bool queue_empty = false; // wave-uniform
+
+    for (;;) {
+        // ---- retire finished chunks, refill idle lanes (wave-aggregated queue pop) ----
+        if (!alive && has_item && s_cur == s_end) {
+            A.partial[item] = r4{acc.x, acc.y, acc.z, R(0)};
+            has_item = false;
+        }
+        const bool need = !alive && !has_item && !queue_empty;
+        const unsigned long long need_mask = __ballot(need);
+        if (need_mask != 0ull) { // wave-uniform
+            const uint32_t n_need = (uint32_t)__popcll(need_mask);
+            unsigned long long base = 0;
+            if (lane == (uint32_t)(__ffsll((long long)need_mask) - 1)) base = atomicAdd(&A.counters[0], (unsigned long long)n_need);
+            base = __shfl(base, __ffsll((long long)need_mask) - 1);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need_mask >> 32),
+                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)need_mask, 0u));
+            const unsigned long long mine = base + rank;
+            if (need && mine < (unsigned long long)A.total_items) {
+                item = (uint32_t)mine;
+                has_item = true;
+                const uint32_t k = item / A.shard_pixels, lp = item - k * A.shard_pixels;
+                const uint32_t lr = lp / A.width;
+                px = lp - lr * A.width;
+                const uint32_t tl = lr / A.tile_rows, within = lr - tl * A.tile_rows;
+                py = (tl * A.shard_count + A.shard_index) * A.tile_rows + within;
+                s_cur = k * A.chunk_spp;
+                s_end = s_cur + A.chunk_spp < A.spp ? s_cur + A.chunk_spp : A.spp;
+                acc = {R(0), R(0), R(0)};
+            }
+            if (base + n_need >= (unsigned long long)A.total_items) queue_empty = true;
+        }
+        if (!alive && has_item) { // start the next path of this lane's chunk
+            const unsigned long long pixel_index = (unsigned long long)py * A.width + px;
+            g.seed_path(A.seed, pixel_index * A.spp + s_cur);
+            camera_ray<R>(A.cam, g, px, py, o, d, time);
+            thr = {R(1), R(1), R(1)};
+            seg = 0;
+            s_cur++;
+            alive = true;
+        }
+        if (__ballot(alive) == 0ull) break; // queue drained and every lane idle: the wave is done
+
+        // ---- nearest hit (full EXEC; idle tail lanes recompute their last ray, results unused) ----
+        R tbest;
+        int ibest;
+        scan_spheres<R>(A.sc, o, d, time, A.tmin, tbest, ibest);
+
+        // ---- shade ----
+        if (alive) {
+            nseg++;
+            seg++;
+            bool cont = shade<R>(A.sc, g, o, d, time, tbest, ibest, thr, acc);
+            if (seg >= A.max_bounces) cont = false; // depth exhausted → contributes black, src/renderer.zig:104-105
+            alive = cont;
+        }
+    }
+    // ---- counters: one atomic per wave ----
+    unsigned long long tot = nseg;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+    if (lane == 0) atomicAdd(&A.counters[1], tot);
+}
+
+// ---- pixel = (Σ_chunks partial) · (1/spp), chunk order: src/renderer.zig:94-95 ---------------------
+template <class R>
+__global__ __launch_bounds__(256) void resolve_kernel(const typename VecOf<R>::type* __restrict__ partial,
+                                                      R* __restrict__ out, uint32_t shard_pixels,
+                                                      uint32_t chunks_per_px, uint32_t spp) {
+    typedef typename VecOf<R>::type r4;
+    const uint32_t lp = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lp >= shard_pixels) return;
+    R x = 0, y = 0, z = 0;
+    for (uint32_t k = 0; k < chunks_per_px; ++k) {
+        const r4 p = partial[(size_t)k * shard_pixels + lp];
+        x = x + p.x;
+        y = y + p.y;
+        z = z + p.z;
+    }
+    const R inv = R(1) / (R)spp;
+    out[3 * (size_t)lp + 0] = x * inv;
+    out[3 * (size_t)lp + 1] = y * inv;
+    out[3 * (size_t)lp + 2] = z * inv;
+}
+
+// ---- `writePPM`'s per-pixel transform, src/image.zig:35-38 + src/vec.zig:79-93 -------------------
+__global__ __launch_bounds__(256) void tonemap_kernel(const float* __restrict__ rgb, uint8_t* __restrict__ out,
+                                                      size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    // in f64, as writePPM computes it on the widened pixel: bit-identical to the host writer
+    const double v = (double)rgb[i];
+    double s = v > 0.0 ? __builtin_sqrt(v) : 0.0;
+    s = s > 0.0 ? s : 0.0; // utils.max(x, low)
+    s = s < 1.0 ? s : 1.0; // utils.min(.., high)
+    out[i] = (uint8_t)(s * 255.0);
+}
+
+} // namespace rayz_dev

@@ -1,0 +1,66 @@
+// rayz — command-line driver with the reference's interface: `rayz <img_w> [out.ppm]`
+// (main, src/rayz.zig:12-43 of jlucier/rayz): build the randomBouncing scene, time render(), print the
+// rate line to stderr, write a P3 PPM to the file or to stdout.
+//
+// Extras the reference does not have (environment variables, so the positional interface stays the
+// reference's): RAYZ_SPP, RAYZ_BOUNCES, RAYZ_SEED, RAYZ_GRID (half-width of the sphere grid, 11 in the
+// reference), RAYZ_PRECISION=f32|f64, RAYZ_TRAVERSAL=linear|bvh.
+#include "rayz.hpp"
+
+#include <chrono>
+#include <cstdlib>
+
+int main(int argc, char** argv) {
+    if (argc < 2) {
+        std::fprintf(stderr, "usage: %s <img_w> [out.ppm]\n", argv[0]); // the reference panics on `.?`, src/rayz.zig:16
+        return 2;
+    }
+    char* end = nullptr;
+    const unsigned long img_w = std::strtoul(argv[1], &end, 10);
+    if (!img_w || (end && *end)) {
+        std::fprintf(stderr, "error: InvalidCharacter\n");
+        return 1;
+    }
+    const char* e;
+    uint64_t seed = 0;
+    const bool has_seed = (e = std::getenv("RAYZ_SEED")) != nullptr;
+    if (has_seed) seed = std::strtoull(e, nullptr, 10);
+    int grid = 11;
+    if ((e = std::getenv("RAYZ_GRID"))) grid = std::atoi(e);
+
+    rayz::Tracer tracer = rayz::randomBouncing(img_w, -grid, grid, has_seed ? &seed : nullptr);
+    if ((e = std::getenv("RAYZ_SPP"))) tracer.samples_per_px = std::strtoul(e, nullptr, 10);
+    if ((e = std::getenv("RAYZ_BOUNCES"))) tracer.max_bounces = std::strtoul(e, nullptr, 10);
+    if ((e = std::getenv("RAYZ_PRECISION")) && std::string(e) == "f64") tracer.gpu.precision = RAYZ_PRECISION_F64;
+    if ((e = std::getenv("RAYZ_TRAVERSAL")) && std::string(e) == "bvh") tracer.gpu.traversal = RAYZ_TRAVERSAL_BVH;
+
+    if (rayz_hip_init(0) != RAYZ_OK) {
+        std::fprintf(stderr, "error: GpuRenderFailed: %s\n", rayz_hip_last_error());
+        return 1;
+    }
+    const auto st = std::chrono::steady_clock::now();
+    double rays_traced;
+    try {
+        rays_traced = (double)tracer.render();
+    } catch (const rayz::GpuRenderFailed& ex) {
+        std::fprintf(stderr, "error: GpuRenderFailed: %s\n", ex.what());
+        return 1;
+    }
+    const double durr = std::chrono::duration<double>(std::chrono::steady_clock::now() - st).count();
+    std::fprintf(stderr, "Finished render (%.2fs): %.2f rps and %.2f us per ray\n", durr, rays_traced / durr,
+                 1e6 * durr / rays_traced); // src/rayz.zig:30-34
+
+    if (argc > 2) {
+        FILE* f = std::fopen(argv[2], "w");
+        if (!f) {
+            std::fprintf(stderr, "error: cannot create %s\n", argv[2]);
+            return 1;
+        }
+        tracer.img.writePPM(f);
+        std::fclose(f);
+    } else {
+        tracer.img.writePPM(stdout);
+    }
+    rayz_hip_shutdown();
+    return 0;
+}

@@ -1,0 +1,82 @@
+"""Device-resident rendering through the C ABI (include/rayz_hip.h).
+
+`DeviceScene` keeps the flattened pool in HBM and renders shards into GPU buffers the caller owns
+(torch tensors in bench.py and the tests) — the split form of `Tracer.render()` that keeps uploads,
+allocation and the host copy out of the timed region.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+
+def init(device: int = 0) -> None:
+    lib = capi.load()
+    capi.check(lib, lib.rayz_hip_init(device), f"rayz_hip_init({device})")
+
+
+def shard_rows(params: capi.RenderParams) -> int:
+    return int(capi.load().rayz_hip_shard_rows(C.byref(params)))
+
+
+def shard_row_indices(height: int, tile_rows: int, shard_index: int, shard_count: int) -> np.ndarray:
+    """Global row numbers of a shard's compact output, in order (host-side bookkeeping of the gather)."""
+    tile_rows = tile_rows or 8
+    shard_count = shard_count or 1
+    rows = np.arange(height)
+    return rows[(rows // tile_rows) % shard_count == shard_index]
+
+
+def render_host(scene: capi.SceneDesc, camera: capi.CameraDesc, params: capi.RenderParams):
+    """One-shot blocking render into host memory: `rayz_hip_render[_f64]`.  Returns (image, stats)."""
+    lib = capi.load()
+    rows = shard_rows(params)
+    f64 = params.precision == capi.PRECISION_F64
+    out = np.empty((rows, params.width, 3), dtype=np.float64 if f64 else np.float32)
+    st = capi.RenderStats()
+    fn = lib.rayz_hip_render_f64 if f64 else lib.rayz_hip_render
+    rc = fn(C.byref(scene), C.byref(camera), C.byref(params), out.ctypes.data_as(C.c_void_p), C.byref(st))
+    capi.check(lib, rc, "rayz_hip_render")
+    return out, st
+
+
+class DeviceScene:
+    """A pool resident in HBM (`rayz_hip_scene_create`)."""
+
+    def __init__(self, scene: capi.SceneDesc):
+        self._lib = capi.load()
+        self._h = C.c_void_p()
+        capi.check(self._lib, self._lib.rayz_hip_scene_create(C.byref(scene), C.byref(self._h)),
+                   "rayz_hip_scene_create")
+
+    def render_into(self, camera: capi.CameraDesc, params: capi.RenderParams, out_ptr: int, stream: int = 0) -> None:
+        """Asynchronous on `stream` (a hipStream_t as int, 0 = the library's stream); `out_ptr` is device memory."""
+        fn = (self._lib.rayz_hip_render_device_f64 if params.precision == capi.PRECISION_F64
+              else self._lib.rayz_hip_render_device)
+        rc = fn(self._h, C.byref(camera), C.byref(params), C.c_void_p(out_ptr), C.c_void_p(stream))
+        capi.check(self._lib, rc, "rayz_hip_render_device")
+
+    def sync(self) -> capi.RenderStats:
+        st = capi.RenderStats()
+        capi.check(self._lib, self._lib.rayz_hip_scene_sync(self._h, C.byref(st)), "rayz_hip_scene_sync")
+        return st
+
+    def close(self) -> None:
+        if self._h:
+            self._lib.rayz_hip_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def tonemap_u8(rgb_ptr: int, out_ptr: int, n_pixels: int, stream: int = 0) -> None:
+    lib = capi.load()
+    capi.check(lib, lib.rayz_hip_tonemap_u8(C.c_void_p(rgb_ptr), C.c_void_p(out_ptr), n_pixels, C.c_void_p(stream)),
+               "rayz_hip_tonemap_u8")
