@@ -579,9 +579,11 @@ template <class R> struct Sph {
     V<R> v;
     double c64[3], v64[3], r2_64; // narrow phase: the pool's own f64 values
     u32 mat;
+    u32 pool; // index in MemPool.spheres
 };
 template <class R> struct SceneB {
-    std::vector<Sph<R>> sph; // device order: static spheres (pool order), then moving spheres (pool order)
+    std::vector<Sph<R>> sph; // scan order (any: the result does not depend on it); here static, then moving
+    std::vector<u32> by_pool; // pool index → position in sph
     u32 n_static = 0;
     std::vector<Mat<R>> mats;
     std::vector<Tex<R>> texs;
@@ -608,10 +610,13 @@ template <class R> static SceneB<R> buildScene(const RayzSceneDesc& d) {
             for (int k = 0; k < 3; ++k) o.c64[k] = q.center[k], o.v64[k] = q.velocity[k];
             o.r2_64 = q.radius * q.radius;
             o.mat = q.material;
+            o.pool = i;
             s.sph.push_back(o);
         }
         if (pass == 0) s.n_static = (u32)s.sph.size();
     }
+    s.by_pool.resize(s.sph.size());
+    for (u32 k = 0; k < s.sph.size(); ++k) s.by_pool[s.sph[k].pool] = k;
     for (u32 i = 0; i < d.n_materials; ++i) {
         const RayzMaterial& m = d.materials[i];
         Mat<R> o;
@@ -719,58 +724,56 @@ static PathResult<R> tracePath(const SceneB<R>& sc, const CamB<R>& cam, const Ra
     for (u32 seg = 0; seg < p.max_bounces; ++seg) {                          // src/renderer.zig:103-126, iterative
         res.segments++;
         // --- nearest hit over the flat list, src/geom.zig:38-66 per sphere ---
-        const R a = dot3(d, d);
+        // Reject test in R with the UNIT direction (disc/a ≥ 0 ⟺ disc ≥ 0); candidates go to the narrow
+        // phase in f64.  Ties in t go to the larger pool index — what the reference's "t ≤ maxt, later wins"
+        // gives over its flat hittable list (src/hit.zig:208-214) — so the result does not depend on the
+        // order in which the spheres are scanned.
+        const V<R> ud = unit(d);
+        const double dx = d.x, dy = d.y, dz = d.z, tm = time;
+        const double a2 = std::fma(dz, dz, std::fma(dy, dy, dx * dx));
+        const double inv_a2 = 1.0 / a2;
         R tbest = inf;
         int ibest = -1;
         const u32 n = (u32)sc.sph.size();
         for (u32 i = 0; i < n; ++i) {
             const Sph<R>& q = sc.sph[i];
             R ocx = q.c.x - o.x, ocy = q.c.y - o.y, ocz = q.c.z - o.z;
-            if (i >= sc.n_static) {
-                ocx = fm(q.v.x, time, ocx);
-                ocy = fm(q.v.y, time, ocy);
-                ocz = fm(q.v.z, time, ocz);
-            }
-            const R hb = fm(d.z, ocz, fm(d.y, ocy, d.x * ocx));
+            if (q.v.x != R(0)) ocx = fm(q.v.x, time, ocx);
+            if (q.v.y != R(0)) ocy = fm(q.v.y, time, ocy);
+            if (q.v.z != R(0)) ocz = fm(q.v.z, time, ocz);
+            const R hbn = fm(ud.z, ocz, fm(ud.y, ocy, ud.x * ocx));
             const R cc = fm(ocz, ocz, fm(ocy, ocy, fm(ocx, ocx, -q.r2)));
-            const R disc = fm(-a, cc, hb * hb);
+            const R disc = fm(hbn, hbn, -cc);
             if (disc >= R(0)) {
-                // narrow phase: the reference's quadratic (src/geom.zig:40-58) in f64 on the f64 sphere,
-                // for the ray as the kernel holds it; roots rounded to R before the range test
-                const double dx = d.x, dy = d.y, dz = d.z, tm = time;
+                // narrow phase: the reference's quadratic (src/geom.zig:40-58) in f64 on the f64 sphere, for
+                // the ray as the kernel holds it; the chosen root is rounded to R before the comparisons
                 double qx = q.c64[0] - (double)o.x, qy = q.c64[1] - (double)o.y, qz = q.c64[2] - (double)o.z;
-                if (i >= sc.n_static) {
-                    qx = std::fma(q.v64[0], tm, qx);
-                    qy = std::fma(q.v64[1], tm, qy);
-                    qz = std::fma(q.v64[2], tm, qz);
-                }
-                const double a2 = std::fma(dz, dz, std::fma(dy, dy, dx * dx));
+                qx = std::fma(q.v64[0], tm, qx);
+                qy = std::fma(q.v64[1], tm, qy);
+                qz = std::fma(q.v64[2], tm, qz);
                 const double hb2 = std::fma(dz, qz, std::fma(dy, qy, dx * qx));
                 const double cc2 = std::fma(qz, qz, std::fma(qy, qy, std::fma(qx, qx, -q.r2_64)));
                 const double disc2 = std::fma(-a2, cc2, hb2 * hb2);
                 if (disc2 >= 0.0) {
                     const double rt = std::sqrt(disc2);
-                    const R t1 = (R)((hb2 - rt) / a2), t2 = (R)((hb2 + rt) / a2);
-                    if (t1 >= tmin && t1 <= tbest) {
-                        tbest = t1;
-                        ibest = (int)i;
-                    } else if (t2 >= tmin && t2 <= tbest) {
-                        tbest = t2;
-                        ibest = (int)i;
+                    const R t1 = (R)((hb2 - rt) * inv_a2), t2 = (R)((hb2 + rt) * inv_a2);
+                    const R t = t1 >= tmin ? t1 : t2;
+                    if (t >= tmin && (t < tbest || (t == tbest && (int)q.pool > ibest))) {
+                        tbest = t;
+                        ibest = (int)q.pool;
                     }
                 }
             }
         }
         if (ibest < 0) {                                                     // miss, src/renderer.zig:124-125
-            const V<R> u = unit(d);
-            const R t = R(0.5) * (u.y + R(1));
+            const R t = R(0.5) * (ud.y + R(1));
             const R w = R(1) - t;
             const V<R> col{(w + R(0.5)) * t, (w + R(0.7)) * t, (w + R(1.0)) * t};
             res.L = {thr.x * col.x, thr.y * col.y, thr.z * col.z};
             return res;
         }
         // --- hit record, src/geom.zig:63-65 + src/hit.zig:25-41 ---
-        const Sph<R>& q = sc.sph[ibest];
+        const Sph<R>& q = sc.sph[sc.by_pool[ibest]];
         const V<R> pt{fm(d.x, tbest, o.x), fm(d.y, tbest, o.y), fm(d.z, tbest, o.z)};
         const V<R> cn{fm(q.v.x, time, q.c.x), fm(q.v.y, time, q.c.y), fm(q.v.z, time, q.c.z)};
         V<R> nrm = unit(V<R>{pt.x - cn.x, pt.y - cn.y, pt.z - cn.z});
@@ -808,7 +811,6 @@ static PathResult<R> tracePath(const SceneB<R>& sc, const CamB<R>& cam, const Ra
             att = textureValue(sc, m.texture, pt);
         } else {                                                             // :137-159
             const R eta = front ? m.inv_param : m.param;
-            const V<R> ud = unit(d);
             const R cosv = -dot3(ud, nrm);
             const R sinv = std::sqrt(fm(-cosv, cosv, R(1)));
             bool refl = eta * sinv > R(1);

@@ -29,24 +29,34 @@ typedef uint32_t u4 __attribute__((ext_vector_type(4)));
 
 constexpr int kMaxRejectionTries = 64;
 constexpr int kMaxTextureDepth = 8;
-constexpr int kStaticUnroll = 4; // static spheres per scan group (records padded to a multiple)
-constexpr int kMovingUnroll = 4; // moving spheres per scan group
+constexpr int kStaticGroup = 4; // spheres per scan group, by velocity class.  A stream is padded to a whole
+constexpr int kMovYGroup = 4;   //   number of group PAIRS plus one spare group, so that the prefetch of the
+constexpr int kMovGGroup = 2;   //   next group never leaves the array.
 
 template <class R> struct VecOf;
 template <> struct VecOf<float> { typedef f4 type; };
 template <> struct VecOf<double> { typedef d4 type; };
 
 // ---- device-resident scene (HBM layout) ------------------------------------------
+// Scan streams, one per velocity class, each padded with never-hit records (r² = -inf):
+//   static  v = 0            stat[i]  = {cx, cy, cz, r²}
+//   mov-Y   v = (0, vy, 0)   movy[i]  = {cx, cy, cz, r²}, movy_vy[i] = vy       (what randomBouncing makes)
+//   mov-G   any other v      movg[2i] = {cx, cy, cz, r²}, movg[2i+1] = {vx, vy, vz, 0}
+// A "slot" numbers the records stat | movy | movg in that order.  The f64 copies feed the narrow phase.
 template <class R> struct DevScene {
     typedef typename VecOf<R>::type r4;
-    const r4* stat;      // [ns_pad]      {cx, cy, cz, r²}; pad records have r² = -inf (never hit)
-    const r4* mov;       // [2 * nm_pad]  {cx, cy, cz, r²}, {vx, vy, vz, 0}
-    const d4* stat64;    // the same records as the pool holds them (f64): narrow phase.  For R = double
-    const d4* mov64;     //   these alias stat / mov.
-    const uint32_t* sphere_mat; // [ns_pad + nm_pad] material index in device order
-    const r4* mat;       // [n_mat] {bits(kind | method << 8), bits(texture), param, 1/param}
-    const r4* tex;       // [2 * n_tex] {bits(kind), bits(even), bits(odd), scale}, {r, g, b, 0}
-    uint32_t ns_pad, nm_pad, n_spheres, _pad;
+    const r4* stat;
+    const r4* movy;
+    const R* movy_vy;
+    const r4* movg;
+    const d4* stat64;        // [ns_pad]      {cx, cy, cz, r²}          (aliases stat for R = double)
+    const d4* movy64;        // [2 * ny_pad]  {cx, cy, cz, r²}, {0, vy, 0, 0}
+    const d4* movg64;        // [2 * ng_pad]  (aliases movg for R = double)
+    const uint32_t* slot_pool; // [slots] pool index of each slot
+    const r4* sph_pool;      // [2 * n_spheres] by POOL index: {cx, cy, cz, r²}, {vx, vy, vz, bits(material)}
+    const r4* mat;           // [n_mat] {bits(kind | method << 8), bits(texture), param, 1/param}
+    const r4* tex;           // [2 * n_tex] {bits(kind), bits(even), bits(odd), scale}, {r, g, b, 0}
+    uint32_t ns_pad, ny_pad, ng_pad, n_spheres;
 };
 
 template <class R> struct DevCamera {
@@ -158,10 +168,12 @@ __device__ __forceinline__ V<R> texture_value(const DevScene<R>& sc, uint32_t id
 
 // ---- narrow phase: one candidate that passed the reject test, src/geom.zig:40-61 ------------------
 // The reference's quadratic in f64 on the pool's f64 sphere, for the ray as the kernel holds it; the
-// roots are rounded to R before the inclusive range test.  `rec` is wave-uniform (scalar loads).
+// chosen root is rounded to R.  Ties in t go to the larger pool index (the reference's "t ≤ maxt, later
+// wins" over its flat list, src/hit.zig:208-214), which makes the result independent of the scan order.
+// `rec` and `pool` are wave-uniform (scalar loads).
 template <class R, bool MOVING>
-__device__ __forceinline__ void narrow_phase(const RAYZ_CONSTANT d4* rec, R disc_fast, V<R> o, V<R> d, R time, R tmin,
-                                             int idx, R& tbest, int& ibest) {
+__device__ __forceinline__ void narrow_phase(const RAYZ_CONSTANT d4* rec, int pool, R disc_fast, V<R> o, V<R> d, R time,
+                                             double inv_a2, R tmin, R& tbest, int& ibest) {
     if (disc_fast >= R(0)) {
         const d4 c = rec[0];
         const double dx = d.x, dy = d.y, dz = d.z;
@@ -179,86 +191,159 @@ __device__ __forceinline__ void narrow_phase(const RAYZ_CONSTANT d4* rec, R disc
         const double disc2 = fm(-a2, cc2, hb2 * hb2);
         if (disc2 >= 0.0) {
             const double rt = __builtin_sqrt(disc2);
-            const R t1 = (R)((hb2 - rt) / a2), t2 = (R)((hb2 + rt) / a2);
-            if (t1 >= tmin && t1 <= tbest) {
-                tbest = t1;
-                ibest = idx;
-            } else if (t2 >= tmin && t2 <= tbest) {
-                tbest = t2;
-                ibest = idx;
+            const R t1 = (R)((hb2 - rt) * inv_a2), t2 = (R)((hb2 + rt) * inv_a2);
+            const R t = t1 >= tmin ? t1 : t2;
+            if (t >= tmin && (t < tbest || (t == tbest && pool > ibest))) {
+                tbest = t;
+                ibest = pool;
             }
         }
     }
 }
 
-// ---- the flat-list scan: nearest hit of ray (o, d, time) over every sphere ---------------------
-// Wave-uniform in the sphere index.  Reject test in R — per static sphere 3 sub + (mul,fma,fma) + 3 fma +
-// (mul,fma) = 11 VALU, per moving sphere +3 fma = 14, plus (3 max + 1 cmp)/4 for the group reject — and
-// narrow_phase() for the few candidates whose line meets the sphere.
-template <class R>
-__device__ __forceinline__ void scan_spheres(const DevScene<R>& sc, V<R> o, V<R> d, R time, R tmin, R& tbest,
-                                             int& ibest) {
+// Reject test of one sphere against the unit direction ud: disc/a = (ud·oc)² − (|oc|² − r²).
+// static: 3 sub + (mul, 2 fma) + 3 fma + 1 fma = 10 VALU; mov-Y +1; mov-G +3.
+template <class R> __device__ __forceinline__ R reject_disc(R ocx, R ocy, R ocz, R r2, V<R> ud) {
+    const R hbn = fm(ud.z, ocz, fm(ud.y, ocy, ud.x * ocx));
+    const R cc = fm(ocz, ocz, fm(ocy, ocy, fm(ocx, ocx, -r2)));
+    return fm(hbn, hbn, -cc);
+}
+
+template <class R, int N> __device__ __forceinline__ R max_of(const R (&v)[N]) {
+    R m = v[0];
+#pragma unroll
+    for (int k = 1; k < N; ++k) m = mx(m, v[k]);
+    return m;
+}
+
+// One scan group of a velocity class, held in SGPRs: load() issues the scalar loads, test() runs the
+// reject test of its spheres against 64 rays and sends candidates to the narrow phase.
+template <class R, int CLS> struct ScanGroup;
+
+template <class R> struct ScanGroup<R, 0> { // static
     typedef typename VecOf<R>::type r4;
-    const RAYZ_CONSTANT r4* stat = (const RAYZ_CONSTANT r4*)sc.stat;
-    const RAYZ_CONSTANT r4* mov = (const RAYZ_CONSTANT r4*)sc.mov;
-    const RAYZ_CONSTANT d4* stat64 = (const RAYZ_CONSTANT d4*)sc.stat64;
-    const RAYZ_CONSTANT d4* mov64 = (const RAYZ_CONSTANT d4*)sc.mov64;
-    const R a = dot3(d, d);
+    static constexpr int G = kStaticGroup;
+    r4 c[G];
+    __device__ __forceinline__ void load(const DevScene<R>& sc, int i) {
+        const RAYZ_CONSTANT r4* p = (const RAYZ_CONSTANT r4*)sc.stat + i;
+#pragma unroll
+        for (int k = 0; k < G; ++k) c[k] = p[k];
+    }
+    __device__ __forceinline__ void touch() const { asm volatile("" ::"s"(c[0].x)); }
+    __device__ __forceinline__ R disc(int k, V<R> o, V<R> ud, R) const {
+        return reject_disc<R>(c[k].x - o.x, c[k].y - o.y, c[k].z - o.z, c[k].w, ud);
+    }
+    static __device__ __forceinline__ const RAYZ_CONSTANT d4* rec64(const DevScene<R>& sc, int i) {
+        return (const RAYZ_CONSTANT d4*)sc.stat64 + i;
+    }
+    static __device__ __forceinline__ int slot0(const DevScene<R>&) { return 0; }
+    static constexpr bool kMoving = false;
+};
+template <class R> struct ScanGroup<R, 1> { // mov-Y
+    typedef typename VecOf<R>::type r4;
+    static constexpr int G = kMovYGroup;
+    r4 c[G];
+    R vy[G];
+    __device__ __forceinline__ void load(const DevScene<R>& sc, int i) {
+        const RAYZ_CONSTANT r4* p = (const RAYZ_CONSTANT r4*)sc.movy + i;
+        const RAYZ_CONSTANT R* q = (const RAYZ_CONSTANT R*)sc.movy_vy + i;
+#pragma unroll
+        for (int k = 0; k < G; ++k) c[k] = p[k], vy[k] = q[k];
+    }
+    __device__ __forceinline__ void touch() const { asm volatile("" ::"s"(c[0].x), "s"(vy[0])); }
+    __device__ __forceinline__ R disc(int k, V<R> o, V<R> ud, R time) const {
+        return reject_disc<R>(c[k].x - o.x, fm(vy[k], time, c[k].y - o.y), c[k].z - o.z, c[k].w, ud);
+    }
+    static __device__ __forceinline__ const RAYZ_CONSTANT d4* rec64(const DevScene<R>& sc, int i) {
+        return (const RAYZ_CONSTANT d4*)sc.movy64 + 2 * i;
+    }
+    static __device__ __forceinline__ int slot0(const DevScene<R>& sc) { return (int)sc.ns_pad; }
+    static constexpr bool kMoving = true;
+};
+template <class R> struct ScanGroup<R, 2> { // mov-G
+    typedef typename VecOf<R>::type r4;
+    static constexpr int G = kMovGGroup;
+    r4 c[G], v[G];
+    __device__ __forceinline__ void load(const DevScene<R>& sc, int i) {
+        const RAYZ_CONSTANT r4* p = (const RAYZ_CONSTANT r4*)sc.movg + 2 * i;
+#pragma unroll
+        for (int k = 0; k < G; ++k) c[k] = p[2 * k], v[k] = p[2 * k + 1];
+    }
+    __device__ __forceinline__ void touch() const { asm volatile("" ::"s"(c[0].x)); }
+    __device__ __forceinline__ R disc(int k, V<R> o, V<R> ud, R time) const {
+        return reject_disc<R>(fm(v[k].x, time, c[k].x - o.x), fm(v[k].y, time, c[k].y - o.y),
+                              fm(v[k].z, time, c[k].z - o.z), c[k].w, ud);
+    }
+    static __device__ __forceinline__ const RAYZ_CONSTANT d4* rec64(const DevScene<R>& sc, int i) {
+        return (const RAYZ_CONSTANT d4*)sc.movg64 + 2 * i;
+    }
+    static __device__ __forceinline__ int slot0(const DevScene<R>& sc) { return (int)(sc.ns_pad + sc.ny_pad); }
+    static constexpr bool kMoving = true;
+};
+
+template <class R, int CLS>
+__device__ __forceinline__ void test_group(const ScanGroup<R, CLS>& g, const DevScene<R>& sc, int i, V<R> o, V<R> d,
+                                           V<R> ud, R time, double inv_a2, R tmin, R& tbest, int& ibest) {
+    constexpr int G = ScanGroup<R, CLS>::G;
+    R disc[G];
+#pragma unroll
+    for (int k = 0; k < G; ++k) disc[k] = g.disc(k, o, ud, time);
+    if (max_of(disc) >= R(0)) { // any lane, any sphere of the group: rare
+        const RAYZ_CONSTANT uint32_t* slot_pool = (const RAYZ_CONSTANT uint32_t*)sc.slot_pool + ScanGroup<R, CLS>::slot0(sc);
+#pragma unroll
+        for (int k = 0; k < G; ++k)
+            narrow_phase<R, ScanGroup<R, CLS>::kMoving>(ScanGroup<R, CLS>::rec64(sc, i + k), (int)slot_pool[i + k], disc[k],
+                                                        o, d, time, inv_a2, tmin, tbest, ibest);
+    }
+}
+
+// One velocity class: n is a multiple of 2·G and the stream carries one spare group, so the loads of
+// the next group are always in flight while the current one is tested (ping-pong SGPR sets a / b).
+template <class R, int CLS>
+__device__ __forceinline__ void scan_class(const DevScene<R>& sc, int n, V<R> o, V<R> d, V<R> ud, R time,
+                                           double inv_a2, R tmin, R& tbest, int& ibest) {
+    constexpr int G = ScanGroup<R, CLS>::G;
+    if (n == 0) return;
+    ScanGroup<R, CLS> a, b;
+    a.load(sc, 0);
+    for (int i = 0; i < n; i += 2 * G) {
+        // Scalar loads return out of order, so a wave can only wait for ALL of them (lgkmcnt(0)).  Order per
+        // half: wait for the group loaded one half earlier (touch), issue the next group's loads, then test —
+        // the sched_barrier keeps hipcc from sinking the loads below the tests.
+        a.touch();
+        b.load(sc, i + G);
+        __builtin_amdgcn_sched_barrier(0);
+        test_group<R, CLS>(a, sc, i, o, d, ud, time, inv_a2, tmin, tbest, ibest);
+        b.touch();
+        a.load(sc, i + 2 * G);
+        __builtin_amdgcn_sched_barrier(0);
+        test_group<R, CLS>(b, sc, i + G, o, d, ud, time, inv_a2, tmin, tbest, ibest);
+    }
+}
+
+// ---- the flat-list scan: nearest hit of ray (o, d, time) over every sphere ---------------------
+// Wave-uniform in the sphere index: records arrive by scalar loads and feed the VALU as SGPR operands.
+template <class R>
+__device__ __forceinline__ void scan_spheres(const DevScene<R>& sc, V<R> o, V<R> d, V<R> ud, R time, R tmin, R& tbest,
+                                             int& ibest) {
+    const double ddx = d.x, ddy = d.y, ddz = d.z;
+    const double inv_a2 = 1.0 / fm(ddz, ddz, fm(ddy, ddy, ddx * ddx));
     tbest = (R)__builtin_inff();
     ibest = -1;
-    const int ns = (int)sc.ns_pad, nm = (int)sc.nm_pad;
-    for (int i = 0; i < ns; i += kStaticUnroll) {
-        R disc[kStaticUnroll];
-#pragma unroll
-        for (int k = 0; k < kStaticUnroll; ++k) {
-            const r4 c = stat[i + k];
-            const R ocx = c.x - o.x, ocy = c.y - o.y, ocz = c.z - o.z;
-            const R hb = fm(d.z, ocz, fm(d.y, ocy, d.x * ocx));
-            const R cc = fm(ocz, ocz, fm(ocy, ocy, fm(ocx, ocx, -c.w)));
-            disc[k] = fm(-a, cc, hb * hb);
-        }
-        R m = disc[0];
-#pragma unroll
-        for (int k = 1; k < kStaticUnroll; ++k) m = mx(m, disc[k]);
-        if (m >= R(0)) {
-#pragma unroll
-            for (int k = 0; k < kStaticUnroll; ++k)
-                narrow_phase<R, false>(stat64 + (i + k), disc[k], o, d, time, tmin, i + k, tbest, ibest);
-        }
-    }
-    for (int i = 0; i < nm; i += kMovingUnroll) {
-        R disc[kMovingUnroll];
-#pragma unroll
-        for (int k = 0; k < kMovingUnroll; ++k) {
-            const r4 c = mov[2 * (i + k)], v = mov[2 * (i + k) + 1];
-            R ocx = c.x - o.x, ocy = c.y - o.y, ocz = c.z - o.z;
-            ocx = fm(v.x, time, ocx);
-            ocy = fm(v.y, time, ocy);
-            ocz = fm(v.z, time, ocz);
-            const R hb = fm(d.z, ocz, fm(d.y, ocy, d.x * ocx));
-            const R cc = fm(ocz, ocz, fm(ocy, ocy, fm(ocx, ocx, -c.w)));
-            disc[k] = fm(-a, cc, hb * hb);
-        }
-        R m = disc[0];
-#pragma unroll
-        for (int k = 1; k < kMovingUnroll; ++k) m = mx(m, disc[k]);
-        if (m >= R(0)) {
-#pragma unroll
-            for (int k = 0; k < kMovingUnroll; ++k)
-                narrow_phase<R, true>(mov64 + 2 * (i + k), disc[k], o, d, time, tmin, ns + i + k, tbest, ibest);
-        }
-    }
+    scan_class<R, 0>(sc, (int)sc.ns_pad, o, d, ud, time, inv_a2, tmin, tbest, ibest);
+    scan_class<R, 1>(sc, (int)sc.ny_pad, o, d, ud, time, inv_a2, tmin, tbest, ibest);
+    scan_class<R, 2>(sc, (int)sc.ng_pad, o, d, ud, time, inv_a2, tmin, tbest, ibest);
 }
 
 // ---- shading of one segment: returns false when the path ends ------------------------------------
 // On a miss adds thr ⊙ background to acc (src/renderer.zig:124-125); on absorption adds nothing.
+// `ibest` is a POOL index; `ud` = unit(d) as the scan used it.
 template <class R>
-__device__ __forceinline__ bool shade(const DevScene<R>& sc, Pcg32& g, V<R>& o, V<R>& d, R time, R tbest, int ibest,
-                                      V<R>& thr, V<R>& acc) {
+__device__ __forceinline__ bool shade(const DevScene<R>& sc, Pcg32& g, V<R>& o, V<R>& d, V<R> ud, R time, R tbest,
+                                      int ibest, V<R>& thr, V<R>& acc) {
     typedef typename VecOf<R>::type r4;
     if (ibest < 0) {
-        const V<R> u = unit(d);
-        const R t = R(0.5) * (u.y + R(1));
+        const R t = R(0.5) * (ud.y + R(1));
         const R w = R(1) - t;
         const V<R> col{(w + R(0.5)) * t, (w + R(0.7)) * t, (w + R(1.0)) * t};
         acc.x = acc.x + thr.x * col.x;
@@ -267,24 +352,15 @@ __device__ __forceinline__ bool shade(const DevScene<R>& sc, Pcg32& g, V<R>& o, 
         return false;
     }
     // hit record: src/geom.zig:63-65, src/hit.zig:25-41
-    V<R> c, v;
-    if (ibest < (int)sc.ns_pad) {
-        const r4 q = sc.stat[ibest];
-        c = {q.x, q.y, q.z};
-        v = {R(0), R(0), R(0)};
-    } else {
-        const int j = ibest - (int)sc.ns_pad;
-        const r4 q = sc.mov[2 * j], w = sc.mov[2 * j + 1];
-        c = {q.x, q.y, q.z};
-        v = {w.x, w.y, w.z};
-    }
+    const r4 q = sc.sph_pool[2 * ibest], w4 = sc.sph_pool[2 * ibest + 1];
+    const V<R> c{q.x, q.y, q.z}, v{w4.x, w4.y, w4.z};
     const V<R> pt{fm(d.x, tbest, o.x), fm(d.y, tbest, o.y), fm(d.z, tbest, o.z)};
     const V<R> cn{fm(v.x, time, c.x), fm(v.y, time, c.y), fm(v.z, time, c.z)};
     V<R> nrm = unit(V<R>{pt.x - cn.x, pt.y - cn.y, pt.z - cn.z});
     const bool front = dot3(nrm, d) < R(0);
     if (!front) nrm = neg(nrm);
 
-    const r4 m = sc.mat[sc.sphere_mat[ibest]];
+    const r4 m = sc.mat[bits(w4.w)];
     const uint32_t kind = bits(m.x) & 0xffu, method = (bits(m.x) >> 8) & 0xffu, texture = bits(m.y);
     const R param = m.z, inv_param = m.w;
     V<R> nd, att;
@@ -315,7 +391,6 @@ __device__ __forceinline__ bool shade(const DevScene<R>& sc, Pcg32& g, V<R>& o, 
         att = texture_value<R>(sc, texture, pt);
     } else { // dielectric, :137-159
         const R eta = front ? inv_param : param;
-        const V<R> ud = unit(d);
         const R cosv = -dot3(ud, nrm);
         const R sinv = sq(fm(-cosv, cosv, R(1)));
         bool refl = eta * sinv > R(1);
@@ -429,13 +504,14 @@ template <class R> __global__ __launch_bounds__(256) void trace_kernel(const Tra
         // ---- nearest hit (full EXEC; idle tail lanes recompute their last ray, results unused) ----
         R tbest;
         int ibest;
-        scan_spheres<R>(A.sc, o, d, time, A.tmin, tbest, ibest);
+        const V<R> ud = unit(d);
+        scan_spheres<R>(A.sc, o, d, ud, time, A.tmin, tbest, ibest);
 
         // ---- shade ----
         if (alive) {
             nseg++;
             seg++;
-            bool cont = shade<R>(A.sc, g, o, d, time, tbest, ibest, thr, acc);
+            bool cont = shade<R>(A.sc, g, o, d, ud, time, tbest, ibest, thr, acc);
             if (seg >= A.max_bounces) cont = false; // depth exhausted → contributes black, src/renderer.zig:104-105
             alive = cont;
         }

@@ -56,24 +56,46 @@ template <> struct Bits<double> {
     }
 };
 
-// Device copy of the scene in one precision.
+// Device copy of the scene in one precision: scan streams + pool-indexed shading tables.
 template <class R> struct SceneBuffers {
     typedef typename VecOf<R>::type r4;
     r4* stat = nullptr;
-    r4* mov = nullptr;
-    uint32_t* sphere_mat = nullptr;
+    r4* movy = nullptr;
+    R* movy_vy = nullptr;
+    r4* movg = nullptr;
+    r4* sph_pool = nullptr;
     r4* mat = nullptr;
     r4* tex = nullptr;
-    uint32_t ns_pad = 0, nm_pad = 0;
     bool ready = false;
     void release() {
         (void)hipFree(stat);
-        (void)hipFree(mov);
-        (void)hipFree(sphere_mat);
+        (void)hipFree(movy);
+        (void)hipFree(movy_vy);
+        (void)hipFree(movg);
+        (void)hipFree(sph_pool);
         (void)hipFree(mat);
         (void)hipFree(tex);
-        stat = mov = mat = tex = nullptr;
-        sphere_mat = nullptr;
+        stat = movy = movg = sph_pool = mat = tex = nullptr;
+        movy_vy = nullptr;
+        ready = false;
+    }
+};
+
+// The pool's own f64 records in slot order (narrow phase) + slot → pool index; shared by both precisions.
+struct NarrowBuffers {
+    d4* stat64 = nullptr;
+    d4* movy64 = nullptr;
+    d4* movg64 = nullptr;
+    uint32_t* slot_pool = nullptr;
+    uint32_t ns_pad = 0, ny_pad = 0, ng_pad = 0;
+    bool ready = false;
+    void release() {
+        (void)hipFree(stat64);
+        (void)hipFree(movy64);
+        (void)hipFree(movg64);
+        (void)hipFree(slot_pool);
+        stat64 = movy64 = movg64 = nullptr;
+        slot_pool = nullptr;
         ready = false;
     }
 };
@@ -88,6 +110,8 @@ struct RayzScene {
     std::vector<RayzTexture> textures;
     SceneBuffers<float> f32;
     SceneBuffers<double> f64;
+    NarrowBuffers narrow;
+    std::vector<uint32_t> cls[3]; // pool indices by velocity class: static, mov-Y, mov-G (pool order inside)
     void* partial = nullptr; // chunk sums, grow-only
     size_t partial_bytes = 0;
     unsigned long long* counters = nullptr; // [0] queue head, [1] segments
@@ -99,40 +123,97 @@ struct RayzScene {
 
 namespace {
 
+template <class T> hipError_t put(T** dst, const std::vector<T>& v) {
+    const size_t bytes = v.size() * sizeof(T);
+    hipError_t e = hipMalloc((void**)dst, bytes ? bytes : 16);
+    if (e != hipSuccess) return e;
+    return bytes ? hipMemcpy(*dst, v.data(), bytes, hipMemcpyHostToDevice) : hipSuccess;
+}
+
+// velocity class of a pool sphere: 0 static, 1 v = (0, vy, 0), 2 anything else
+int velocity_class(const RayzSphere& q) {
+    const bool x = q.velocity[0] != 0, y = q.velocity[1] != 0, z = q.velocity[2] != 0;
+    if (!x && !y && !z) return 0;
+    return (!x && !z) ? 1 : 2;
+}
+
+void classify(RayzScene* s) {
+    for (auto& c : s->cls) c.clear();
+    for (uint32_t i = 0; i < s->spheres.size(); ++i) s->cls[velocity_class(s->spheres[i])].push_back(i);
+}
+
+// scanned length of a stream (whole group pairs) and its allocated length (+ one spare group for the prefetch)
+uint32_t scan_len(size_t n, uint32_t group) { return round_up((uint32_t)n, 2 * group); }
+uint32_t stream_len(size_t n, uint32_t group) { return scan_len(n, group) + group; }
+
+int upload_narrow(RayzScene* s) {
+    NarrowBuffers& nb = s->narrow;
+    if (nb.ready) return RAYZ_OK;
+    classify(s);
+    nb.ns_pad = scan_len(s->cls[0].size(), kStaticGroup);
+    nb.ny_pad = scan_len(s->cls[1].size(), kMovYGroup);
+    nb.ng_pad = scan_len(s->cls[2].size(), kMovGGroup);
+    const double ninf = -std::numeric_limits<double>::infinity();
+    std::vector<d4> stat64(nb.ns_pad, d4{0, 0, 0, ninf}), movy64(2 * (size_t)nb.ny_pad, d4{0, 0, 0, 0}),
+        movg64(2 * (size_t)nb.ng_pad, d4{0, 0, 0, 0});
+    std::vector<uint32_t> slot_pool((size_t)nb.ns_pad + nb.ny_pad + nb.ng_pad, 0u);
+    for (uint32_t k = 0; k < nb.ny_pad; ++k) movy64[2 * k].w = ninf;
+    for (uint32_t k = 0; k < nb.ng_pad; ++k) movg64[2 * k].w = ninf;
+    auto rec = [&](uint32_t pool) {
+        const RayzSphere& q = s->spheres[pool];
+        return d4{q.center[0], q.center[1], q.center[2], q.radius * q.radius}; // radius * radius in f64, src/geom.zig:45
+    };
+    auto vel = [&](uint32_t pool) {
+        const RayzSphere& q = s->spheres[pool];
+        return d4{q.velocity[0], q.velocity[1], q.velocity[2], 0.0};
+    };
+    for (size_t k = 0; k < s->cls[0].size(); ++k) stat64[k] = rec(s->cls[0][k]), slot_pool[k] = s->cls[0][k];
+    for (size_t k = 0; k < s->cls[1].size(); ++k)
+        movy64[2 * k] = rec(s->cls[1][k]), movy64[2 * k + 1] = vel(s->cls[1][k]), slot_pool[nb.ns_pad + k] = s->cls[1][k];
+    for (size_t k = 0; k < s->cls[2].size(); ++k)
+        movg64[2 * k] = rec(s->cls[2][k]), movg64[2 * k + 1] = vel(s->cls[2][k]),
+        slot_pool[nb.ns_pad + nb.ny_pad + k] = s->cls[2][k];
+    HIP_TRY(put(&nb.stat64, stat64));
+    HIP_TRY(put(&nb.movy64, movy64));
+    HIP_TRY(put(&nb.movg64, movg64));
+    HIP_TRY(put(&nb.slot_pool, slot_pool));
+    nb.ready = true;
+    return RAYZ_OK;
+}
+
 template <class R> int upload(RayzScene* s, SceneBuffers<R>& b) {
     typedef typename VecOf<R>::type r4;
     if (b.ready) return RAYZ_OK;
+    int rc = upload_narrow(s);
+    if (rc != RAYZ_OK) return rc;
     const R ninf = -std::numeric_limits<R>::infinity();
-    std::vector<r4> stat, mov;
-    std::vector<uint32_t> smat, mmat;
-    for (const RayzSphere& q : s->spheres) {
-        const bool moving = q.velocity[0] != 0 || q.velocity[1] != 0 || q.velocity[2] != 0;
-        const R r = (R)q.radius; // r² in R: for R = double this is the reference's radius * radius, src/geom.zig:45
-        const r4 c = {(R)q.center[0], (R)q.center[1], (R)q.center[2], r * r};
-        if (!moving) {
-            stat.push_back(c);
-            smat.push_back(q.material);
-        } else {
-            mov.push_back(c);
-            mov.push_back(r4{(R)q.velocity[0], (R)q.velocity[1], (R)q.velocity[2], R(0)});
-            mmat.push_back(q.material);
-        }
+    const r4 pad = {R(0), R(0), R(0), ninf}; // r² = -inf: the discriminant is -inf (or NaN), never ≥ 0
+    auto rec = [&](uint32_t pool) {
+        const RayzSphere& q = s->spheres[pool];
+        const R r = (R)q.radius;
+        return r4{(R)q.center[0], (R)q.center[1], (R)q.center[2], r * r};
+    };
+    std::vector<r4> stat(stream_len(s->cls[0].size(), kStaticGroup), pad);
+    std::vector<r4> movy(stream_len(s->cls[1].size(), kMovYGroup), pad);
+    std::vector<R> movy_vy(movy.size(), R(0));
+    std::vector<r4> movg(2 * (size_t)stream_len(s->cls[2].size(), kMovGGroup), r4{R(0), R(0), R(0), R(0)});
+    for (size_t k = 0; k < movg.size(); k += 2) movg[k] = pad;
+    for (size_t k = 0; k < s->cls[0].size(); ++k) stat[k] = rec(s->cls[0][k]);
+    for (size_t k = 0; k < s->cls[1].size(); ++k) {
+        movy[k] = rec(s->cls[1][k]);
+        movy_vy[k] = (R)s->spheres[s->cls[1][k]].velocity[1];
     }
-    b.ns_pad = round_up((uint32_t)stat.size(), kStaticUnroll);
-    b.nm_pad = round_up((uint32_t)mmat.size(), kMovingUnroll);
-    const r4 pad = {R(0), R(0), R(0), ninf}; // r² = -inf: discriminant is -inf (or NaN), never ≥ 0
-    while (stat.size() < b.ns_pad) {
-        stat.push_back(pad);
-        smat.push_back(0);
+    for (size_t k = 0; k < s->cls[2].size(); ++k) {
+        const RayzSphere& q = s->spheres[s->cls[2][k]];
+        movg[2 * k] = rec(s->cls[2][k]);
+        movg[2 * k + 1] = r4{(R)q.velocity[0], (R)q.velocity[1], (R)q.velocity[2], R(0)};
     }
-    while (mmat.size() < b.nm_pad) {
-        mov.push_back(pad);
-        mov.push_back(r4{R(0), R(0), R(0), R(0)});
-        mmat.push_back(0);
+    std::vector<r4> sph_pool, mat, tex;
+    for (uint32_t i = 0; i < s->spheres.size(); ++i) {
+        const RayzSphere& q = s->spheres[i];
+        sph_pool.push_back(rec(i));
+        sph_pool.push_back(r4{(R)q.velocity[0], (R)q.velocity[1], (R)q.velocity[2], Bits<R>::from(q.material)});
     }
-    std::vector<uint32_t> sphere_mat(smat);
-    sphere_mat.insert(sphere_mat.end(), mmat.begin(), mmat.end());
-    std::vector<r4> mat, tex;
     for (const RayzMaterial& m : s->materials) {
         const R p = (R)m.param;
         mat.push_back(r4{Bits<R>::from(m.kind | (m.method << 8)), Bits<R>::from(m.texture), p, R(1) / p});
@@ -141,15 +222,11 @@ template <class R> int upload(RayzScene* s, SceneBuffers<R>& b) {
         tex.push_back(r4{Bits<R>::from(t.kind), Bits<R>::from(t.even), Bits<R>::from(t.odd), (R)t.scale});
         tex.push_back(r4{(R)t.color[0], (R)t.color[1], (R)t.color[2], R(0)});
     }
-    auto put = [](auto** dst, const auto& v) -> hipError_t {
-        const size_t bytes = v.size() * sizeof(v[0]);
-        hipError_t e = hipMalloc((void**)dst, bytes ? bytes : 16);
-        if (e != hipSuccess) return e;
-        return bytes ? hipMemcpy(*dst, v.data(), bytes, hipMemcpyHostToDevice) : hipSuccess;
-    };
     HIP_TRY(put(&b.stat, stat));
-    HIP_TRY(put(&b.mov, mov));
-    HIP_TRY(put(&b.sphere_mat, sphere_mat));
+    HIP_TRY(put(&b.movy, movy));
+    HIP_TRY(put(&b.movy_vy, movy_vy));
+    HIP_TRY(put(&b.movg, movg));
+    HIP_TRY(put(&b.sph_pool, sph_pool));
     HIP_TRY(put(&b.mat, mat));
     HIP_TRY(put(&b.tex, tex));
     b.ready = true;
@@ -250,22 +327,19 @@ int render_impl(RayzScene* s, SceneBuffers<R>& b, const RayzCameraDesc* cam, con
 
     TraceArgs<R> A{};
     A.sc.stat = b.stat;
-    A.sc.mov = b.mov;
-    if (sizeof(R) == sizeof(double)) {
-        A.sc.stat64 = (const d4*)b.stat;
-        A.sc.mov64 = (const d4*)b.mov;
-    } else {
-        rc = upload<double>(s, s->f64); // narrow phase reads the pool's f64 records
-        if (rc != RAYZ_OK) return rc;
-        if (s->f64.ns_pad != b.ns_pad || s->f64.nm_pad != b.nm_pad) return fail(RAYZ_ERR_STATE, "f32/f64 layouts differ");
-        A.sc.stat64 = s->f64.stat;
-        A.sc.mov64 = s->f64.mov;
-    }
-    A.sc.sphere_mat = b.sphere_mat;
+    A.sc.movy = b.movy;
+    A.sc.movy_vy = b.movy_vy;
+    A.sc.movg = b.movg;
+    A.sc.stat64 = s->narrow.stat64;
+    A.sc.movy64 = s->narrow.movy64;
+    A.sc.movg64 = s->narrow.movg64;
+    A.sc.slot_pool = s->narrow.slot_pool;
+    A.sc.sph_pool = b.sph_pool;
     A.sc.mat = b.mat;
     A.sc.tex = b.tex;
-    A.sc.ns_pad = b.ns_pad;
-    A.sc.nm_pad = b.nm_pad;
+    A.sc.ns_pad = s->narrow.ns_pad;
+    A.sc.ny_pad = s->narrow.ny_pad;
+    A.sc.ng_pad = s->narrow.ng_pad;
     A.sc.n_spheres = (uint32_t)s->spheres.size();
     fill_camera<R>(cam, A.cam);
     A.partial = (r4*)s->partial;
@@ -418,6 +492,7 @@ int rayz_hip_scene_destroy(RayzScene* s) {
     if (s->last_stream || g_stream) (void)hipStreamSynchronize(s->last_stream ? s->last_stream : g_stream);
     s->f32.release();
     s->f64.release();
+    s->narrow.release();
     (void)hipFree(s->partial);
     (void)hipFree(s->counters);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
