@@ -109,29 +109,21 @@ def main():
               precision=capi.PRECISION_F64 if args.precision == "f64" else capi.PRECISION_F32,
               traversal=capi.TRAVERSAL_BVH if args.traversal == "bvh" else capi.TRAVERSAL_LINEAR)
     scene, cam, p = t.scene_desc(), t.camera_desc(), t.params()
-    p.tile_rows, p.shard_index, p.shard_count = 8, rank, world
+    from rayz_amd import dist as rdist
+
+    p = rdist.shard_params(p, rank, world)
     H, W = p.height, p.width
-    rows = render.shard_rows(p)
-    max_rows = max(len(render.shard_row_indices(H, 8, r, world)) for r in range(world))
     dtype = torch.float64 if args.precision == "f64" else torch.float32
     dev = torch.device("cuda", local_rank)
-    tile = torch.zeros((max_rows, W, 3), dtype=dtype, device=dev)  # this rank's rows, padded to the max
-    gathered = torch.empty((world, max_rows, W, 3), dtype=dtype, device=dev) if world > 1 else None
-    frame = torch.empty((H, W, 3), dtype=dtype, device=dev)
-    row_index = [torch.as_tensor(render.shard_row_indices(H, 8, r, world), device=dev) for r in range(world)]
+    fg = rdist.FrameGather(H, W, world, rank, dev, dtype=dtype)  # this rank's row tiles + the gathered frame
     dscene = render.DeviceScene(scene)
     stream = torch.cuda.current_stream().cuda_stream
 
     kernel_ms, seg_total = [], []
 
     def step(record: bool):
-        dscene.render_into(cam, p, tile.data_ptr(), stream)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, tile)
-            for r in range(world):
-                frame[row_index[r]] = gathered[r, : len(row_index[r])]
-        else:
-            frame.copy_(tile[:H])
+        dscene.render_into(cam, p, fg.tile.data_ptr(), stream)
+        fg.gather()  # N > 1: one RCCL all_gather of the f32 row tiles + un-interleave; N = 1: a copy
         if record:  # per-step kernel time from the library's HIP events on this stream (forces a sync)
             st = dscene.sync()
             kernel_ms.append(st.kernel_ms)

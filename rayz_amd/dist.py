@@ -1,0 +1,59 @@
+"""Multi-GPU sharding of a frame: interleaved row tiles, one process per GPU, one framebuffer gather.
+
+The path shards embarrassingly (every pixel-sample has its own PCG32 stream keyed by the GLOBAL pixel index,
+so the image does not depend on how rows are dealt out).  Rows go to ranks in interleaved tiles of `tile_rows`
+rows — contiguous bands would be badly balanced, sky rows finish in one segment per sample — and the only
+collective is one all_gather of the ranks' compact row blocks at the end (RCCL over xGMI with backend "nccl";
+the same code runs on gloo for the CPU tests).  The reference has no counterpart: it is single-threaded.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import capi, render
+
+DEFAULT_TILE_ROWS = 8
+
+
+def shard_params(params: capi.RenderParams, rank: int, world: int, tile_rows: int = DEFAULT_TILE_ROWS) -> capi.RenderParams:
+    """A copy of `params` restricted to rank's rows."""
+    p = capi.RenderParams.from_buffer_copy(bytes(params))
+    p.tile_rows, p.shard_index, p.shard_count = tile_rows, rank, world
+    return p
+
+
+def max_shard_rows(height: int, world: int, tile_rows: int = DEFAULT_TILE_ROWS) -> int:
+    return max(len(render.shard_row_indices(height, tile_rows, r, world)) for r in range(world))
+
+
+class FrameGather:
+    """Pre-allocated buffers + index maps for gathering row-tile shards into the full frame on every rank."""
+
+    def __init__(self, height: int, width: int, world: int, rank: int, device, dtype=torch.float32,
+                 tile_rows: int = DEFAULT_TILE_ROWS, group=None):
+        self.h, self.w, self.world, self.rank, self.group = height, width, world, rank, group
+        self.rows = [render.shard_row_indices(height, tile_rows, r, world) for r in range(world)]
+        self.max_rows = max(len(r) for r in self.rows)
+        self.tile = torch.zeros((self.max_rows, width, 3), dtype=dtype, device=device)  # this rank's rows (padded)
+        self.frame = torch.empty((height, width, 3), dtype=dtype, device=device)
+        self._idx = [torch.as_tensor(r, device=device, dtype=torch.long) for r in self.rows]
+        # concatenated along dim 0 (the form both RCCL and gloo accept); viewed per rank when scattering rows
+        self._gathered = (torch.empty((world * self.max_rows, width, 3), dtype=dtype, device=device)
+                          if world > 1 else None)
+
+    @property
+    def my_rows(self) -> np.ndarray:
+        return self.rows[self.rank]
+
+    def gather(self) -> torch.Tensor:
+        """all_gather the tiles and un-interleave them; returns the full frame (valid on every rank)."""
+        if self.world == 1:
+            self.frame.copy_(self.tile[: self.h])
+            return self.frame
+        dist.all_gather_into_tensor(self._gathered, self.tile, group=self.group)
+        parts = self._gathered.view(self.world, self.max_rows, self.w, 3)
+        for r in range(self.world):
+            self.frame.index_copy_(0, self._idx[r], parts[r, : len(self.rows[r])])
+        return self.frame

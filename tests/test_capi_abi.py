@@ -1,0 +1,121 @@
+"""The C-ABI library loads on a machine without a GPU and exports exactly what include/*.h declares;
+argument checking and error reporting work without touching a device.  No compute calls here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from rayz_amd import capi, render, tracer
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rayz_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(built):
+    lib = capi.load()
+    names = declared_symbols("rayz_hip.h") + declared_symbols("rayz_host.h")
+    assert len(names) >= 35
+    for n in names:
+        assert hasattr(lib, n), f"{n} is declared in include/ but not exported by librayz_hip.so"
+
+
+def test_binding_covers_every_declared_symbol(built):
+    bound = {p[0] for p in capi.PROTOTYPES} | {p[0] for p in tracer.HOST_PROTOTYPES}
+    declared = set(declared_symbols("rayz_hip.h") + declared_symbols("rayz_host.h"))
+    assert declared == bound, (declared - bound, bound - declared)
+
+
+def test_abi_version_and_struct_sizes(built):
+    lib = capi.load()
+    assert lib.rayz_hip_abi_version() == capi.ABI_VERSION == 1
+    # sizes the Zig extern structs must reproduce
+    assert (C.sizeof(capi.Texture), C.sizeof(capi.Material), C.sizeof(capi.Sphere)) == (48, 24, 64)
+    assert (C.sizeof(capi.SceneDesc), C.sizeof(capi.CameraDesc)) == (40, 152)
+    assert (C.sizeof(capi.RenderParams), C.sizeof(capi.RenderStats)) == (56, 40)
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    with pytest.raises(capi.RayzHipError, match="no CPU fallback"):
+        capi.load(str(tmp_path / "nope.so"))
+
+
+@pytest.mark.parametrize("h,tile,count", [(1080, 8, 1), (1080, 8, 8), (2160, 8, 8), (225, 8, 2), (7, 8, 3), (1, 1, 1),
+                                          (100, 16, 5)])
+def test_shard_rows_partition_the_image(built, h, tile, count):
+    lib = capi.load()
+    seen = []
+    for idx in range(count):
+        p = capi.RenderParams(width=4, height=h, samples_per_px=1, tile_rows=tile, shard_index=idx, shard_count=count)
+        rows = render.shard_row_indices(h, tile, idx, count)
+        assert lib.rayz_hip_shard_rows(C.byref(p)) == len(rows)
+        seen.extend(rows.tolist())
+    assert sorted(seen) == list(range(h))
+
+
+def test_shard_rows_rejects_bad_index(built):
+    lib = capi.load()
+    p = capi.RenderParams(width=4, height=10, samples_per_px=1, shard_index=3, shard_count=2)
+    assert lib.rayz_hip_shard_rows(C.byref(p)) == 0
+
+
+def test_scene_validation_without_a_device(built):
+    """Bad handles are rejected with RAYZ_ERR_BAD_ARG and a message, before any HIP call."""
+    lib = capi.load()
+    t = tracer.threeSpheres(64, seed=1)
+    sd = t.scene_desc()
+    h = C.c_void_p()
+    assert lib.rayz_hip_scene_create(C.byref(sd), C.byref(h)) == capi.OK
+    assert lib.rayz_hip_scene_destroy(h) == capi.OK
+    # sphere with a material handle out of range
+    bad = (capi.Sphere * 1)(capi.Sphere(center=capi.D3(0, 0, 0), velocity=capi.D3(0, 0, 0), radius=1, material=7))
+    sd2 = capi.SceneDesc(spheres=bad, materials=sd.materials, textures=sd.textures, n_spheres=1,
+                         n_materials=sd.n_materials, n_textures=sd.n_textures)
+    assert lib.rayz_hip_scene_create(C.byref(sd2), C.byref(h)) == capi.ERR_BAD_ARG
+    assert b"material handle 7" in lib.rayz_hip_last_error()
+    assert lib.rayz_hip_scene_create(None, C.byref(h)) == capi.ERR_BAD_ARG
+    # checker texture pointing outside the list
+    tex = (capi.Texture * 1)(capi.Texture(kind=capi.TEX_CHECKER, even=0, odd=5, scale=1.0))
+    sd3 = capi.SceneDesc(spheres=None, materials=None, textures=tex, n_textures=1)
+    assert lib.rayz_hip_scene_create(C.byref(sd3), C.byref(h)) == capi.ERR_BAD_ARG
+
+
+def test_render_without_device_is_an_error_not_a_fallback(built):
+    """On a box with no GPU the render entry points must fail (NO_DEVICE), never compute on the CPU."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present; covered by the gpu tests")
+    lib = capi.load()
+    assert lib.rayz_hip_init(0) == capi.ERR_NO_DEVICE
+    t = tracer.threeSpheres(32, seed=1)
+    t.samples_per_px = 1
+    out = np.full((18, 32, 3), -1.0, dtype=np.float32)
+    rc = lib.rayz_hip_render(C.byref(t.scene_desc()), C.byref(t.camera_desc()), C.byref(t.params()),
+                             out.ctypes.data_as(C.c_void_p), None)
+    assert rc == capi.ERR_NO_DEVICE
+    assert (out == -1.0).all()
+    with pytest.raises(capi.RayzHipError):
+        t.render()
+
+
+def test_param_validation(built):
+    lib = capi.load()
+    t = tracer.threeSpheres(32, seed=1)
+    out = np.zeros((18, 32, 3), dtype=np.float32)
+    p = t.params()
+    p.samples_per_px = 0
+    rc = lib.rayz_hip_render(C.byref(t.scene_desc()), C.byref(t.camera_desc()), C.byref(p),
+                             out.ctypes.data_as(C.c_void_p), None)
+    assert rc == capi.ERR_BAD_ARG
+    p = t.params()
+    p.precision = 9
+    rc = lib.rayz_hip_render(C.byref(t.scene_desc()), C.byref(t.camera_desc()), C.byref(p),
+                             out.ctypes.data_as(C.c_void_p), None)
+    assert rc == capi.ERR_BAD_ARG and b"precision" in lib.rayz_hip_last_error()

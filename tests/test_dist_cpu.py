@@ -1,0 +1,62 @@
+"""The N > 1 path on CPU: two gloo ranks shard a frame by interleaved row tiles, each "renders" its rows (with
+the oracle standing in for the GPU, test-side only), one all_gather reassembles the frame, and the result is
+identical to the unsharded image.  Exercises rayz_amd/dist.py exactly as bench.py uses it."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, tile_rows, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import binding as oracle
+        from rayz_amd import dist as rdist
+        from rayz_amd import tracer
+
+        t = tracer.randomBouncing(40, -2, 2, seed=5)
+        t.samples_per_px, t.max_bounces = 3, 6
+        t.set_gpu(render_seed=8)
+        sd, cam, p = t.scene_desc(), t.camera_desc(), t.params()
+        fg = rdist.FrameGather(p.height, p.width, world, rank, torch.device("cpu"), tile_rows=tile_rows)
+        mine, _ = oracle.render_b(sd, cam, rdist.shard_params(p, rank, world, tile_rows), threads=1)
+        assert mine.shape[0] == len(fg.my_rows)
+        fg.tile[: mine.shape[0]] = torch.from_numpy(mine)
+        frame = fg.gather().numpy().copy()
+        if rank == 0:
+            full, _ = oracle.render_b(sd, cam, p, threads=1)
+            q.put(bool(np.array_equal(frame, full)))
+        # every rank holds the whole frame
+        chk = torch.tensor([float(frame.sum())], dtype=torch.float64)
+        lst = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(lst, chk)
+        assert all(float(x) == float(lst[0]) for x in lst)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,tile_rows", [(2, 8), (2, 3), (3, 4)])
+def test_row_tile_shard_and_gather_gloo(built, world, tile_rows):
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = 29500 + (os.getpid() * 7 + world * 13 + tile_rows) % 2000
+    mp.spawn(_worker, args=(world, port, tile_rows, q), nprocs=world, join=True)
+    assert q.get() is True
+
+
+def test_frame_gather_single_rank(built):
+    from rayz_amd import dist as rdist
+
+    fg = rdist.FrameGather(10, 4, 1, 0, torch.device("cpu"))
+    fg.tile.copy_(torch.arange(10 * 4 * 3, dtype=torch.float32).reshape(10, 4, 3))
+    assert torch.equal(fg.gather(), fg.tile)
+    assert rdist.max_shard_rows(1080, 8) == 136 and rdist.max_shard_rows(2160, 8) == 272
