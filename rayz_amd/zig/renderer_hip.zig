@@ -1,0 +1,158 @@
+//! renderer_hip.zig — Zig-side drop-in for the loop nest of `Tracer.render()` (src/renderer.zig:72-101).
+//!
+//! SOURCE ONLY: there is no Zig toolchain in the build image, so this file has never been compiled.
+//! The C++ mirror (rayz_amd/host/rayz.hpp `Tracer::render`) performs exactly these steps and is what the
+//! test-suite exercises.  Written against the Zig 0.13/0.14 std the reference uses.
+//!
+//! Usage in the reference tree: copy next to src/renderer.zig, link librayz_hip.so
+//! (`exe.addLibraryPath(...)`, `exe.linkSystemLibrary("rayz_hip")`, `exe.linkLibC()` in build.zig), and
+//! replace the body of `Tracer.render` by `return renderHip(self, .{});`.
+
+const std = @import("std");
+const vec = @import("./vec.zig");
+const mat = @import("./material.zig");
+const renderer = @import("./renderer.zig");
+
+// ---- include/rayz_hip.h, field for field (extern struct = C layout) ----
+pub const RayzTexture = extern struct {
+    kind: u32, // 0 checker, 1 solid: tag order of `Texture = union(enum)`, src/material.zig:41-44
+    even: u32,
+    odd: u32,
+    _pad: u32 = 0,
+    scale: f64,
+    color: [3]f64,
+};
+pub const RayzMaterial = extern struct {
+    kind: u32, // 0 diffuse, 1 metallic, 2 dielectric: src/material.zig:162-165
+    texture: u32,
+    method: u32, // DiffuseScatterMethod, src/material.zig:67-71
+    _pad: u32 = 0,
+    param: f64, // fuzz | refractive_index
+};
+pub const RayzSphere = extern struct {
+    center: [3]f64,
+    velocity: [3]f64,
+    radius: f64,
+    material: u32,
+    _pad: u32 = 0,
+};
+pub const RayzSceneDesc = extern struct {
+    spheres: ?[*]const RayzSphere,
+    materials: ?[*]const RayzMaterial,
+    textures: ?[*]const RayzTexture,
+    n_spheres: u32,
+    n_materials: u32,
+    n_textures: u32,
+    _pad: u32 = 0,
+};
+pub const RayzCameraDesc = extern struct {
+    look_from: [3]f64,
+    px_du: [3]f64,
+    px_dv: [3]f64,
+    px_origin: [3]f64,
+    defocus_u: [3]f64,
+    defocus_v: [3]f64,
+    defocus: u32,
+    _pad: u32 = 0,
+};
+pub const RayzRenderParams = extern struct {
+    width: u32,
+    height: u32,
+    samples_per_px: u32,
+    max_bounces: u32,
+    seed: u64,
+    tmin: f64,
+    precision: u32 = 0, // 0 f32 (tmin 1e-3), 1 f64 (the reference's 1e-10)
+    traversal: u32 = 0, // 0 flat list, 1 BVH
+    chunk_spp: u32 = 0,
+    tile_rows: u32 = 0,
+    shard_index: u32 = 0,
+    shard_count: u32 = 0,
+};
+pub const RayzRenderStats = extern struct {
+    primary_rays: u64,
+    segments: u64,
+    sphere_tests: u64,
+    node_tests: u64,
+    kernel_ms: f64,
+};
+
+extern "c" fn rayz_hip_init(device: c_int) c_int;
+extern "c" fn rayz_hip_last_error() [*:0]const u8;
+extern "c" fn rayz_hip_render(
+    scene: *const RayzSceneDesc,
+    camera: *const RayzCameraDesc,
+    params: *const RayzRenderParams,
+    rgb_out: [*]f32,
+    stats: ?*RayzRenderStats,
+) c_int;
+
+fn v3(v: vec.V3) [3]f64 {
+    return .{ v.x, v.y, v.z };
+}
+
+pub const HipOptions = struct {
+    seed: ?u64 = null, // null: next u64 of the Tracer's own DefaultPrng
+    tmin: f64 = 1e-3,
+};
+
+/// The body of `Tracer.render()`: flatten → one extern call → widen f32 → f64 into img.pixels.
+pub fn renderHip(self: *renderer.Tracer, opt: HipOptions) !usize {
+    const a = self.allocator;
+    // Zig structs / unions have no defined layout: copy field by field (SURVEY.md §8b "Layout caveat").
+    const spheres = try a.alloc(RayzSphere, self.pool.spheres.items.len);
+    defer a.free(spheres);
+    for (self.pool.spheres.items, spheres) |s, *o| o.* = .{
+        .center = v3(s.center.origin),
+        .velocity = v3(s.center.dir),
+        .radius = s.radius,
+        .material = @intCast(s.material.idx),
+    };
+    const materials = try a.alloc(RayzMaterial, self.pool.materials.items.len);
+    defer a.free(materials);
+    for (self.pool.materials.items, materials) |m, *o| o.* = switch (m) {
+        .diffuse => |d| .{ .kind = 0, .texture = @intCast(d.texture.idx), .method = @intFromEnum(d.method), .param = 0 },
+        .metallic => |d| .{ .kind = 1, .texture = @intCast(d.texture.idx), .method = 2, .param = d.fuzz },
+        .dielectric => |d| .{ .kind = 2, .texture = 0, .method = 2, .param = d.refractive_index },
+    };
+    const textures = try a.alloc(RayzTexture, self.pool.textures.items.len);
+    defer a.free(textures);
+    for (self.pool.textures.items, textures) |t, *o| o.* = switch (t) {
+        .checker => |c| .{ .kind = 0, .even = @intCast(c.even.idx), .odd = @intCast(c.odd.idx), .scale = c.scale, .color = .{ 0, 0, 0 } },
+        .solid => |s| .{ .kind = 1, .even = 0, .odd = 0, .scale = 0, .color = v3(s.color) },
+    };
+    const scene = RayzSceneDesc{
+        .spheres = spheres.ptr,
+        .materials = materials.ptr,
+        .textures = textures.ptr,
+        .n_spheres = @intCast(spheres.len),
+        .n_materials = @intCast(materials.len),
+        .n_textures = @intCast(textures.len),
+    };
+    const cam = RayzCameraDesc{
+        .look_from = v3(self.camera.look_from),
+        .px_du = v3(self.camera.px_du),
+        .px_dv = v3(self.camera.px_dv),
+        .px_origin = v3(self.camera.px_origin),
+        .defocus_u = v3(self.camera.defocus_u),
+        .defocus_v = v3(self.camera.defocus_v),
+        .defocus = @intFromBool(self.camera.defocus),
+    };
+    const params = RayzRenderParams{
+        .width = @intCast(self.img.w),
+        .height = @intCast(self.img.h),
+        .samples_per_px = @intCast(self.samples_per_px),
+        .max_bounces = @intCast(self.max_bounces),
+        .seed = opt.seed orelse self.rng.random().int(u64),
+        .tmin = opt.tmin,
+    };
+    const rgb = try a.alloc(f32, self.img.w * self.img.h * 3);
+    defer a.free(rgb);
+    var stats: RayzRenderStats = undefined;
+    if (rayz_hip_init(0) != 0 or rayz_hip_render(&scene, &cam, &params, rgb.ptr, &stats) != 0) {
+        std.debug.print("rayz_hip: {s}\n", .{rayz_hip_last_error()});
+        return error.GpuRenderFailed;
+    }
+    for (self.img.pixels, 0..) |*px, i| px.* = .{ .x = rgb[3 * i], .y = rgb[3 * i + 1], .z = rgb[3 * i + 2] };
+    return @intCast(stats.primary_rays); // what render() returns, src/renderer.zig:90,100
+}
