@@ -160,6 +160,13 @@ uint32_t rayz_hip_shard_rows(const RayzRenderParams* p);
 int rayz_hip_scene_create(const RayzSceneDesc* scene, RayzScene** out);
 int rayz_hip_scene_destroy(RayzScene* scene);
 
+/* The BVH `render()` would build (src/renderer.zig:76-78 -> src/hit.zig:130-161), flattened in depth-first
+ * pre-order with skip links as the GPU traverses it.  Host only (no device needed).  Call once with every array
+ * NULL to get *n_nodes, then with arrays of n_nodes (boxes: 6 doubles per node, lo then hi; skip/first/count:
+ * one u32 per node; order: n_spheres pool indices in leaf order).  count == 0 marks an inner node. */
+int rayz_hip_scene_bvh(RayzScene* scene, uint32_t* n_nodes, uint32_t* depth, double* boxes, uint32_t* skip,
+                       uint32_t* first, uint32_t* count, uint32_t* order);
+
 /* Replaces the loop nest src/renderer.zig:80-97.  Asynchronous on `hip_stream` (a hipStream_t, or
  * NULL for the library's own stream); `d_rgb_out` is DEVICE memory, rows_in_shard*width*3 floats,
  * row-major packed RGB, linear radiance means as `img.pixels` holds them (src/renderer.zig:94-95;

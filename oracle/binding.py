@@ -43,6 +43,7 @@ def load() -> C.CDLL:
         "rayz_oracle_render_b_f64": (C.c_int, [S, Cm, Pm, _P(C.c_uint32), C.c_uint32, C.c_void_p, St, C.c_int]),
         "rayz_oracle_shard_rows": (C.c_uint32, [Pm]),
         "rayz_oracle_render_a": (C.c_int, [S, Cm, Pm, C.c_uint32, C.c_uint32, _U64, C.c_int, _D, _D, St]),
+        "rayz_oracle_bvh_flat": (C.c_uint32, [S, _D, _P(C.c_uint32), _P(C.c_uint32), _P(C.c_uint32), _P(C.c_uint32)]),
         "rayz_oracle_camera_init": (None, [C.c_double, C.c_double, C.c_double, _D, _D, _D, C.c_uint32, C.c_uint32, Cm]),
         "rayz_oracle_get_ray_norng": (None, [Cm, C.c_uint32, C.c_uint32, _D, _D]),
         "rayz_oracle_refract": (None, [_D, _D, C.c_double, _D]),

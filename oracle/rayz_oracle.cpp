@@ -585,6 +585,14 @@ template <class R> struct SceneB {
     std::vector<Sph<R>> sph; // scan order (any: the result does not depend on it); here static, then moving
     std::vector<u32> by_pool; // pool index → position in sph
     u32 n_static = 0;
+    // BVH traversal: the mode-A tree (src/hit.zig:130-161) in depth-first pre-order with skip links; boxes
+    // narrowed outward to R
+    struct Node {
+        R lo[3], hi[3];
+        u32 skip, first, count;
+    };
+    std::vector<Node> nodes;
+    std::vector<u32> leaf_order; // pool indices in leaf order
     std::vector<Mat<R>> mats;
     std::vector<Tex<R>> texs;
 };
@@ -640,6 +648,49 @@ template <class R> static SceneB<R> buildScene(const RayzSceneDesc& d) {
     return s;
 }
 
+template <class R> static R roundDown(double v) {
+    R r = (R)v;
+    if ((double)r > v) r = std::nextafter(r, -std::numeric_limits<R>::infinity());
+    return r;
+}
+template <class R> static R roundUp(double v) {
+    R r = (R)v;
+    if ((double)r < v) r = std::nextafter(r, std::numeric_limits<R>::infinity());
+    return r;
+}
+
+// index one past the subtree of node ni (pre-order layout)
+static u32 subtreeEnd(const A::BVH& t, int ni) {
+    const A::BVH::Node& n = t.nodes[ni];
+    return n.left < 0 ? (u32)ni + 1 : subtreeEnd(t, n.right);
+}
+
+template <class R> static void buildBvh(const RayzSceneDesc& d, SceneB<R>& s) {
+    if (d.n_spheres == 0) return;
+    A::Scene sa;
+    for (u32 i = 0; i < d.n_spheres; ++i) {
+        A::Sphere q;
+        q.center.origin = A::v3(d.spheres[i].center);
+        q.center.dir = A::v3(d.spheres[i].velocity);
+        q.radius = d.spheres[i].radius;
+        q.material = d.spheres[i].material;
+        sa.spheres.push_back(q);
+    }
+    for (u32 i = 0; i < d.n_spheres; ++i) sa.hittables.push_back({sa.spheres[i].boundingBox(), i});
+    A::BVH t;
+    t.build(sa.hittables, 0, sa.hittables.size());
+    for (size_t i = 0; i < t.nodes.size(); ++i) {
+        const A::BVH::Node& n = t.nodes[i];
+        typename SceneB<R>::Node o;
+        for (int k = 0; k < 3; ++k) o.lo[k] = roundDown<R>(n.bbox.low.at(k)), o.hi[k] = roundUp<R>(n.bbox.high.at(k));
+        o.skip = subtreeEnd(t, (int)i);
+        o.first = n.left < 0 ? (u32)n.starti : 0;
+        o.count = n.left < 0 ? (u32)(n.endi - n.starti) : 0;
+        s.nodes.push_back(o);
+    }
+    for (const A::Hittable& h : sa.hittables) s.leaf_order.push_back(h.sphere);
+}
+
 template <class R> static CamB<R> buildCamera(const RayzCameraDesc& d) {
     CamB<R> c;
     c.from = narrow3<R>(d.look_from);
@@ -686,6 +737,7 @@ template <class R> static V<R> textureValue(const SceneB<R>& sc, u32 idx, V<R> p
 template <class R> struct PathResult {
     V<R> L;
     u32 segments;
+    u64 node_tests, sphere_tests;
 };
 
 template <class R>
@@ -718,7 +770,7 @@ static PathResult<R> tracePath(const SceneB<R>& sc, const CamB<R>& cam, const Ra
     const R time = g.uniform();
 
     V<R> thr{1, 1, 1};
-    PathResult<R> res{{0, 0, 0}, 0};
+    PathResult<R> res{{0, 0, 0}, 0, 0, 0};
     const R inf = std::numeric_limits<R>::infinity();
 
     for (u32 seg = 0; seg < p.max_bounces; ++seg) {                          // src/renderer.zig:103-126, iterative
@@ -734,9 +786,8 @@ static PathResult<R> tracePath(const SceneB<R>& sc, const CamB<R>& cam, const Ra
         const double inv_a2 = 1.0 / a2;
         R tbest = inf;
         int ibest = -1;
-        const u32 n = (u32)sc.sph.size();
-        for (u32 i = 0; i < n; ++i) {
-            const Sph<R>& q = sc.sph[i];
+        // one sphere: reject test in R, candidates through the f64 quadratic
+        auto testSphere = [&](const Sph<R>& q) {
             R ocx = q.c.x - o.x, ocy = q.c.y - o.y, ocz = q.c.z - o.z;
             if (q.v.x != R(0)) ocx = fm(q.v.x, time, ocx);
             if (q.v.y != R(0)) ocy = fm(q.v.y, time, ocy);
@@ -744,26 +795,54 @@ static PathResult<R> tracePath(const SceneB<R>& sc, const CamB<R>& cam, const Ra
             const R hbn = fm(ud.z, ocz, fm(ud.y, ocy, ud.x * ocx));
             const R cc = fm(ocz, ocz, fm(ocy, ocy, fm(ocx, ocx, -q.r2)));
             const R disc = fm(hbn, hbn, -cc);
-            if (disc >= R(0)) {
-                // narrow phase: the reference's quadratic (src/geom.zig:40-58) in f64 on the f64 sphere, for
-                // the ray as the kernel holds it; the chosen root is rounded to R before the comparisons
-                double qx = q.c64[0] - (double)o.x, qy = q.c64[1] - (double)o.y, qz = q.c64[2] - (double)o.z;
-                qx = std::fma(q.v64[0], tm, qx);
-                qy = std::fma(q.v64[1], tm, qy);
-                qz = std::fma(q.v64[2], tm, qz);
-                const double hb2 = std::fma(dz, qz, std::fma(dy, qy, dx * qx));
-                const double cc2 = std::fma(qz, qz, std::fma(qy, qy, std::fma(qx, qx, -q.r2_64)));
-                const double disc2 = std::fma(-a2, cc2, hb2 * hb2);
-                if (disc2 >= 0.0) {
-                    const double rt = std::sqrt(disc2);
-                    const R t1 = (R)((hb2 - rt) * inv_a2), t2 = (R)((hb2 + rt) * inv_a2);
-                    const R t = t1 >= tmin ? t1 : t2;
-                    if (t >= tmin && (t < tbest || (t == tbest && (int)q.pool > ibest))) {
-                        tbest = t;
-                        ibest = (int)q.pool;
+            if (!(disc >= R(0))) return;
+            // narrow phase: the reference's quadratic (src/geom.zig:40-58) in f64 on the f64 sphere, for the ray
+            // as the kernel holds it; the chosen root is rounded to R before the comparisons
+            double qx = q.c64[0] - (double)o.x, qy = q.c64[1] - (double)o.y, qz = q.c64[2] - (double)o.z;
+            qx = std::fma(q.v64[0], tm, qx);
+            qy = std::fma(q.v64[1], tm, qy);
+            qz = std::fma(q.v64[2], tm, qz);
+            const double hb2 = std::fma(dz, qz, std::fma(dy, qy, dx * qx));
+            const double cc2 = std::fma(qz, qz, std::fma(qy, qy, std::fma(qx, qx, -q.r2_64)));
+            const double disc2 = std::fma(-a2, cc2, hb2 * hb2);
+            if (!(disc2 >= 0.0)) return;
+            const double rt = std::sqrt(disc2);
+            const R t1 = (R)((hb2 - rt) * inv_a2), t2 = (R)((hb2 + rt) * inv_a2);
+            const R t = t1 >= tmin ? t1 : t2;
+            if (t >= tmin && (t < tbest || (t == tbest && (int)q.pool > ibest))) {
+                tbest = t;
+                ibest = (int)q.pool;
+            }
+        };
+        if (p.traversal == RAYZ_TRAVERSAL_BVH) {
+            // src/hit.zig:181-216 as a skip-link walk; slab test src/hit.zig:70-98 with 1/d hoisted and a
+            // 4-ulp slack (never culls a box the f64 narrow phase would hit)
+            const V<R> inv{R(1) / d.x, R(1) / d.y, R(1) / d.z};
+            const R slack = R(1) + R(4) * std::numeric_limits<R>::epsilon();
+            const u32 nn = (u32)sc.nodes.size();
+            u32 idx = 0;
+            while (idx < nn) {
+                const typename SceneB<R>::Node& nd = sc.nodes[idx];
+                res.node_tests++;
+                const R ax = (nd.lo[0] - o.x) * inv.x, bx = (nd.hi[0] - o.x) * inv.x;
+                const R ay = (nd.lo[1] - o.y) * inv.y, by = (nd.hi[1] - o.y) * inv.y;
+                const R az = (nd.lo[2] - o.z) * inv.z, bz = (nd.hi[2] - o.z) * inv.z;
+                const R t0 = std::fmax(std::fmax(std::fmin(ax, bx), std::fmin(ay, by)), std::fmax(std::fmin(az, bz), tmin));
+                const R t1 = std::fmin(std::fmin(std::fmax(ax, bx), std::fmax(ay, by)), std::fmin(std::fmax(az, bz), tbest));
+                u32 next = nd.skip;
+                if (t1 * slack >= t0) {
+                    if (nd.count == 0) next = idx + 1;
+                    for (u32 k = 0; k < nd.count; ++k) {
+                        res.sphere_tests++;
+                        testSphere(sc.sph[sc.by_pool[sc.leaf_order[nd.first + k]]]);
                     }
                 }
+                idx = next;
             }
+        } else {
+            const u32 n = (u32)sc.sph.size();
+            res.sphere_tests += n;
+            for (u32 i = 0; i < n; ++i) testSphere(sc.sph[i]);
         }
         if (ibest < 0) {                                                     // miss, src/renderer.zig:124-125
             const R t = R(0.5) * (ud.y + R(1));
@@ -859,7 +938,8 @@ static int render(const RayzSceneDesc* sd, const RayzCameraDesc* cd, const RayzR
     if (!sd || !cd || !pp || !out) return RAYZ_ERR_BAD_ARG;
     const RayzRenderParams p = *pp;
     if (!p.width || !p.height || !p.samples_per_px) return RAYZ_ERR_BAD_ARG;
-    const SceneB<R> sc = buildScene<R>(*sd);
+    SceneB<R> sc = buildScene<R>(*sd);
+    if (p.traversal == RAYZ_TRAVERSAL_BVH) buildBvh<R>(*sd, sc);
     const CamB<R> cam = buildCamera<R>(*cd);
     const u32 C = p.chunk_spp ? p.chunk_spp : 16;
     std::vector<u32> pixels; // global pixel indices, in output order
@@ -870,11 +950,11 @@ static int render(const RayzSceneDesc* sd, const RayzCameraDesc* cd, const RayzR
         for (u32 r : rows)
             for (u32 i = 0; i < p.width; ++i) pixels.push_back(r * p.width + i);
     }
-    u64 segs = 0;
+    u64 segs = 0, ntests = 0, stests = 0;
     const long np = (long)pixels.size();
 #ifdef _OPENMP
     if (threads > 0) omp_set_num_threads(threads);
-#pragma omp parallel for schedule(dynamic, 16) reduction(+ : segs)
+#pragma omp parallel for schedule(dynamic, 16) reduction(+ : segs, ntests, stests)
 #endif
     for (long k = 0; k < np; ++k) {
         const u32 px = pixels[k] % p.width, py = pixels[k] / p.width;
@@ -886,6 +966,8 @@ static int render(const RayzSceneDesc* sd, const RayzCameraDesc* cd, const RayzR
                 const PathResult<R> r = tracePath<R>(sc, cam, p, px, py, s);
                 acc = {acc.x + r.L.x, acc.y + r.L.y, acc.z + r.L.z};
                 segs += r.segments;
+                ntests += r.node_tests;
+                stests += r.sphere_tests;
             }
             pix = {pix.x + acc.x, pix.y + acc.y, pix.z + acc.z};
         }
@@ -898,8 +980,8 @@ static int render(const RayzSceneDesc* sd, const RayzCameraDesc* cd, const RayzR
     if (stats) {
         stats->primary_rays = (u64)np * p.samples_per_px;
         stats->segments = segs;
-        stats->sphere_tests = segs * sd->n_spheres;
-        stats->node_tests = 0;
+        stats->sphere_tests = stests;
+        stats->node_tests = ntests;
         stats->kernel_ms = 0;
     }
     return RAYZ_OK;
@@ -991,6 +1073,27 @@ int rayz_oracle_render_a(const RayzSceneDesc* sd, const RayzCameraDesc* cd, cons
         stats->kernel_ms = 0;
     }
     return RAYZ_OK;
+}
+
+// ---- the BVH `render()` builds (src/renderer.zig:76-78), flattened in pre-order with skip links ----
+// Arrays may be NULL; returns the node count.  boxes: 6 doubles per node (low, high).
+uint32_t rayz_oracle_bvh_flat(const RayzSceneDesc* sd, double* boxes, uint32_t* skip, uint32_t* first, uint32_t* count,
+                              uint32_t* order) {
+    if (!sd || sd->n_spheres == 0) return 0;
+    A::Scene sc = sceneA(*sd);
+    A::BVH t;
+    t.build(sc.hittables, 0, sc.hittables.size());
+    for (size_t i = 0; i < t.nodes.size(); ++i) {
+        const A::BVH::Node& n = t.nodes[i];
+        if (boxes)
+            for (int k = 0; k < 3; ++k) boxes[6 * i + k] = n.bbox.low.at(k), boxes[6 * i + 3 + k] = n.bbox.high.at(k);
+        if (skip) skip[i] = B::subtreeEnd(t, (int)i);
+        if (first) first[i] = n.left < 0 ? (u32)n.starti : 0;
+        if (count) count[i] = n.left < 0 ? (u32)(n.endi - n.starti) : 0;
+    }
+    if (order)
+        for (size_t i = 0; i < sc.hittables.size(); ++i) order[i] = sc.hittables[i].sphere;
+    return (uint32_t)t.nodes.size();
 }
 
 // ---- pieces the reference's own tests pin ----

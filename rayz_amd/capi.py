@@ -80,6 +80,9 @@ PROTOTYPES = [
     ("rayz_hip_shard_rows", C.c_uint32, [C.POINTER(RenderParams)]),
     ("rayz_hip_scene_create", C.c_int, [C.POINTER(SceneDesc), C.POINTER(C.c_void_p)]),
     ("rayz_hip_scene_destroy", C.c_int, [C.c_void_p]),
+    ("rayz_hip_scene_bvh", C.c_int,
+     [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.POINTER(C.c_uint32),
+      C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("rayz_hip_render_device", C.c_int,
      [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderParams), C.c_void_p, C.c_void_p]),
     ("rayz_hip_render_device_f64", C.c_int,

@@ -1,0 +1,115 @@
+// bvh_build.hpp — host build of the reference's BVH, flattened for stackless GPU traversal.
+//
+// The tree is the one `BVH.build` makes (src/hit.zig:130-161 of jlucier/rayz): hittables in pool order
+// (src/ecs.zig:43-51) with `Sphere.boundingBox` boxes (src/geom.zig:24-31: union of the boxes at time 0 and
+// 1), node box = union of its hittables' boxes, leaves of ≤ 2, otherwise a STABLE sort (std.mem.sort) of the
+// node's range by `bbox.low[axis]` on the box's longest axis (`amax` tie rule, src/vec.zig:150-156) and a
+// split at nobjs/2.  It is then laid out in depth-first pre-order (left subtree first — the order
+// `findHit` visits, src/hit.zig:195-204) with a skip link per node: "hit → next node in memory, miss → skip"
+// walks the same nodes as the reference's recursion, with no stack.
+#pragma once
+
+#include "../../include/rayz_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <limits>
+#include <vector>
+
+namespace rayz_bvh {
+
+struct Box {
+    double lo[3], hi[3];
+    Box() {
+        for (int k = 0; k < 3; ++k) lo[k] = std::numeric_limits<double>::infinity(), hi[k] = -lo[k];
+    }
+    void enclose(const Box& o) { // AABB.enclose, src/hit.zig:55-60
+        for (int k = 0; k < 3; ++k) lo[k] = std::fmin(lo[k], o.lo[k]), hi[k] = std::fmax(hi[k], o.hi[k]);
+    }
+    int longestAxis() const { // src/hit.zig:62-64 + V3.amax
+        const double x = hi[0] - lo[0], y = hi[1] - lo[1], z = hi[2] - lo[2];
+        if (x > y) return x > z ? 0 : 2;
+        return y > z ? 1 : 2;
+    }
+};
+
+inline Box sphereBox(const RayzSphere& s) { // Sphere.boundingBox, src/geom.zig:24-31
+    Box b;
+    for (int k = 0; k < 3; ++k) {
+        const double o1 = s.center[k], o2 = s.center[k] + s.velocity[k] * 1.0; // center.at(1)
+        const double a1 = std::fmin(o1 - s.radius, o1 + s.radius), b1 = std::fmax(o1 - s.radius, o1 + s.radius);
+        const double a2 = std::fmin(o2 - s.radius, o2 + s.radius), b2 = std::fmax(o2 - s.radius, o2 + s.radius);
+        b.lo[k] = std::fmin(a1, a2);
+        b.hi[k] = std::fmax(b1, b2);
+    }
+    return b;
+}
+
+struct FlatNode {
+    Box box;
+    uint32_t skip;  // index of the next node when this subtree is done or culled (== n_nodes at the end)
+    uint32_t first; // leaves: first entry in `order`
+    uint32_t count; // leaves: 1 or 2; inner nodes: 0
+};
+
+struct FlatBvh {
+    std::vector<FlatNode> nodes;  // depth-first pre-order
+    std::vector<uint32_t> order;  // pool indices of the hittables after the in-place sorts, i.e. leaf order
+    uint32_t depth = 0;
+};
+
+namespace detail {
+struct Item {
+    Box box;
+    uint32_t pool;
+};
+inline void build(std::vector<Item>& h, size_t si, size_t ei, FlatBvh& out, uint32_t depth) {
+    const size_t me = out.nodes.size();
+    out.nodes.push_back(FlatNode{});
+    out.depth = std::max(out.depth, depth);
+    Box bb;
+    for (size_t i = si; i < ei; ++i) bb.enclose(h[i].box);
+    const size_t nobjs = ei - si;
+    if (nobjs <= 2) {
+        out.nodes[me].box = bb;
+        out.nodes[me].first = (uint32_t)si;
+        out.nodes[me].count = (uint32_t)nobjs;
+    } else {
+        const int ax = bb.longestAxis();
+        std::stable_sort(h.begin() + si, h.begin() + ei,
+                         [ax](const Item& a, const Item& b) { return a.box.lo[ax] < b.box.lo[ax]; });
+        const size_t mid = nobjs / 2 + si;
+        out.nodes[me].box = bb;
+        out.nodes[me].count = 0;
+        build(h, si, mid, out, depth + 1);
+        build(h, mid, ei, out, depth + 1);
+    }
+    out.nodes[me].skip = (uint32_t)out.nodes.size();
+}
+} // namespace detail
+
+inline FlatBvh build(const std::vector<RayzSphere>& spheres) {
+    FlatBvh out;
+    if (spheres.empty()) return out;
+    std::vector<detail::Item> h(spheres.size());
+    for (size_t i = 0; i < spheres.size(); ++i) h[i] = {sphereBox(spheres[i]), (uint32_t)i};
+    detail::build(h, 0, h.size(), out, 1);
+    out.order.resize(h.size());
+    for (size_t i = 0; i < h.size(); ++i) out.order[i] = h[i].pool;
+    return out;
+}
+
+// Conservative narrowing of a box bound to R: never shrinks the box.
+template <class R> inline R roundDown(double v) {
+    R r = (R)v;
+    if ((double)r > v) r = std::nextafter(r, -std::numeric_limits<R>::infinity());
+    return r;
+}
+template <class R> inline R roundUp(double v) {
+    R r = (R)v;
+    if ((double)r < v) r = std::nextafter(r, std::numeric_limits<R>::infinity());
+    return r;
+}
+
+} // namespace rayz_bvh

@@ -57,6 +57,11 @@ template <class R> struct DevScene {
     const r4* mat;           // [n_mat] {bits(kind | method << 8), bits(texture), param, 1/param}
     const r4* tex;           // [2 * n_tex] {bits(kind), bits(even), bits(odd), scale}, {r, g, b, 0}
     uint32_t ns_pad, ny_pad, ng_pad, n_spheres;
+    // BVH traversal (RAYZ_TRAVERSAL_BVH): the reference's tree in depth-first pre-order, DESIGN.md §6
+    const r4* bvh_nodes;     // [2 * n_nodes] {lo.x, lo.y, lo.z, bits(skip)}, {hi.x, hi.y, hi.z, bits(first << 2 | count)}
+    const r4* bvh_sph;       // [2 * n_spheres] leaf order: {cx, cy, cz, r²}, {vx, vy, vz, bits(pool)}
+    const d4* bvh_sph64;     // [2 * n_spheres] leaf order: {cx, cy, cz, r²}, {vx, vy, vz, 0}
+    uint32_t bvh_n_nodes, _pad0, _pad1, _pad2;
 };
 
 template <class R> struct DevCamera {
@@ -68,7 +73,7 @@ template <class R> struct TraceArgs {
     DevScene<R> sc;
     DevCamera<R> cam;
     typename VecOf<R>::type* partial; // [total_items] chunk sums
-    unsigned long long* counters;     // [0] work-queue head, [1] segments
+    unsigned long long* counters;     // [0] work-queue head, [1] segments, [2] node tests, [3] sphere tests (BVH)
     unsigned long long seed;
     R tmin;
     uint32_t width, height, spp, max_bounces;
@@ -521,6 +526,186 @@ template <class R> __global__ __launch_bounds__(256) void trace_kernel(const Tra
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
     if (lane == 0) atomicAdd(&A.counters[1], tot);
+}
+
+// ---- BVH traversal (src/hit.zig:181-216, recursion → skip links) -----------------------------------
+// Per-lane state of one nearest-hit query over the flattened tree.
+template <class R> struct BvhQuery {
+    V<R> inv;       // 1 / d per component
+    double inv_a2;  // 1 / (d·d) in f64 for the narrow phase
+    R tbest;
+    int ibest;      // pool index
+    uint32_t idx;   // next node; >= n_nodes: done
+};
+
+template <class R> __device__ __forceinline__ void bvh_begin(BvhQuery<R>& q, V<R> d) {
+    q.inv = {R(1) / d.x, R(1) / d.y, R(1) / d.z};
+    const double ddx = d.x, ddy = d.y, ddz = d.z;
+    q.inv_a2 = 1.0 / fm(ddz, ddz, fm(ddy, ddy, ddx * ddx));
+    q.tbest = (R)__builtin_inff();
+    q.ibest = -1;
+    q.idx = 0;
+}
+
+template <class R> struct Slack;
+template <> struct Slack<float> { static constexpr float v = 1.0f + 4.0f * 1.1920929e-07f; };
+template <> struct Slack<double> { static constexpr double v = 1.0 + 4.0 * 2.220446049250313e-16; };
+
+__device__ __forceinline__ float mn(float a, float b) { return __builtin_fminf(a, b); }
+__device__ __forceinline__ double mn(double a, double b) { return __builtin_fmin(a, b); }
+
+// One node step of a lane: slab test (AABB.hit, src/hit.zig:70-98, with 1/d hoisted and a 4-ulp slack so that
+// rounding never culls a box the f64 narrow phase would hit), then either descend, test the leaf's ≤ 2 spheres,
+// or follow the skip link.
+template <class R>
+__device__ __forceinline__ void bvh_step(const DevScene<R>& sc, BvhQuery<R>& q, V<R> o, V<R> d, V<R> ud, R time, R tmin,
+                                         uint32_t& node_tests, uint32_t& sphere_tests) {
+    typedef typename VecOf<R>::type r4;
+    const r4 a = sc.bvh_nodes[2 * q.idx], b = sc.bvh_nodes[2 * q.idx + 1];
+    node_tests++;
+    const R ax = (a.x - o.x) * q.inv.x, bx = (b.x - o.x) * q.inv.x;
+    const R ay = (a.y - o.y) * q.inv.y, by = (b.y - o.y) * q.inv.y;
+    const R az = (a.z - o.z) * q.inv.z, bz = (b.z - o.z) * q.inv.z;
+    const R t0 = mx(mx(mn(ax, bx), mn(ay, by)), mx(mn(az, bz), tmin));
+    const R t1 = mn(mn(mx(ax, bx), mx(ay, by)), mn(mx(az, bz), q.tbest));
+    uint32_t next = bits(a.w);
+    if (t1 * Slack<R>::v >= t0) {
+        const uint32_t leaf = bits(b.w);
+        const uint32_t cnt = leaf & 3u, first = leaf >> 2;
+        if (cnt == 0u) next = q.idx + 1u;
+        for (uint32_t k = 0; k < cnt; ++k) {
+            const r4 c = sc.bvh_sph[2 * (first + k)], v = sc.bvh_sph[2 * (first + k) + 1];
+            sphere_tests++;
+            const R disc = reject_disc<R>(fm(v.x, time, c.x - o.x), fm(v.y, time, c.y - o.y), fm(v.z, time, c.z - o.z),
+                                          c.w, ud);
+            if (disc >= R(0)) {
+                const d4 c2 = sc.bvh_sph64[2 * (first + k)], v2 = sc.bvh_sph64[2 * (first + k) + 1];
+                const double dx = d.x, dy = d.y, dz = d.z, tm = time;
+                const double qx = fm(v2.x, tm, c2.x - (double)o.x), qy = fm(v2.y, tm, c2.y - (double)o.y),
+                             qz = fm(v2.z, tm, c2.z - (double)o.z);
+                const double a2 = fm(dz, dz, fm(dy, dy, dx * dx));
+                const double hb2 = fm(dz, qz, fm(dy, qy, dx * qx));
+                const double cc2 = fm(qz, qz, fm(qy, qy, fm(qx, qx, -c2.w)));
+                const double disc2 = fm(-a2, cc2, hb2 * hb2);
+                if (disc2 >= 0.0) {
+                    const double rt = __builtin_sqrt(disc2);
+                    const R t1r = (R)((hb2 - rt) * q.inv_a2), t2r = (R)((hb2 + rt) * q.inv_a2);
+                    const R t = t1r >= tmin ? t1r : t2r;
+                    const int pool = (int)bits(v.w);
+                    if (t >= tmin && (t < q.tbest || (t == q.tbest && pool > q.ibest))) {
+                        q.tbest = t;
+                        q.ibest = pool;
+                    }
+                }
+            }
+        }
+    }
+    q.idx = next;
+}
+
+// ---- persistent trace kernel, BVH traversal ------------------------------------------------------
+// Same work items, queue and summation tree as trace_kernel.  Traversal is per lane (divergent), so lanes
+// finish at different times: the node loop runs while at least kBvhKeepActive/64 of the wave is still
+// walking; when fewer remain, the finished lanes are shaded and refilled (ray regeneration) while the
+// unfinished ones keep their query state and resume — the wave never idles behind one long traversal.
+constexpr int kBvhKeepActive = 40;
+
+template <class R> __global__ __launch_bounds__(256) void trace_kernel_bvh(const TraceArgs<R> A) {
+    typedef typename VecOf<R>::type r4;
+    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const uint32_t n_nodes = A.sc.bvh_n_nodes;
+    Pcg32 g{0, 1};
+    V<R> o{0, 0, 0}, d{0, 0, 1}, ud{0, 0, 1}, thr{1, 1, 1}, acc{0, 0, 0};
+    BvhQuery<R> q;
+    q.inv = {R(1), R(1), R(1)};
+    q.inv_a2 = 1.0;
+    q.tbest = R(0);
+    q.ibest = -1;
+    q.idx = n_nodes;
+    R time = 0;
+    uint32_t item = 0, px = 0, py = 0, s_cur = 0, s_end = 0, seg = 0, nseg = 0, node_tests = 0, sphere_tests = 0;
+    bool has_item = false, alive = false;
+    bool queue_empty = false; // wave-uniform
+
+    for (;;) {
+        // ---- retire finished chunks, refill idle lanes (wave-aggregated queue pop) ----
+        if (!alive && has_item && s_cur == s_end) {
+            A.partial[item] = r4{acc.x, acc.y, acc.z, R(0)};
+            has_item = false;
+        }
+        const bool need = !alive && !has_item && !queue_empty;
+        const unsigned long long need_mask = __ballot(need);
+        if (need_mask != 0ull) {
+            const uint32_t n_need = (uint32_t)__popcll(need_mask);
+            const int leader = __ffsll((long long)need_mask) - 1;
+            unsigned long long base = 0;
+            if ((int)lane == leader) base = atomicAdd(&A.counters[0], (unsigned long long)n_need);
+            base = __shfl(base, leader);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need_mask >> 32),
+                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)need_mask, 0u));
+            const unsigned long long mine = base + rank;
+            if (need && mine < (unsigned long long)A.total_items) {
+                item = (uint32_t)mine;
+                has_item = true;
+                const uint32_t k = item / A.shard_pixels, lp = item - k * A.shard_pixels;
+                const uint32_t lr = lp / A.width;
+                px = lp - lr * A.width;
+                const uint32_t tl = lr / A.tile_rows, within = lr - tl * A.tile_rows;
+                py = (tl * A.shard_count + A.shard_index) * A.tile_rows + within;
+                s_cur = k * A.chunk_spp;
+                s_end = s_cur + A.chunk_spp < A.spp ? s_cur + A.chunk_spp : A.spp;
+                acc = {R(0), R(0), R(0)};
+            }
+            if (base + n_need >= (unsigned long long)A.total_items) queue_empty = true;
+        }
+        if (!alive && has_item) {
+            const unsigned long long pixel_index = (unsigned long long)py * A.width + px;
+            g.seed_path(A.seed, pixel_index * A.spp + s_cur);
+            camera_ray<R>(A.cam, g, px, py, o, d, time);
+            thr = {R(1), R(1), R(1)};
+            seg = 0;
+            s_cur++;
+            alive = true;
+            ud = unit(d);
+            bvh_begin<R>(q, d);
+        }
+        if (__ballot(alive) == 0ull) break;
+
+        // ---- node loop: runs while enough of the wave is still walking ----
+        const int n_alive = __popcll(__ballot(alive));
+        for (;;) {
+            const bool walking = alive && q.idx < n_nodes;
+            const int n_walking = __popcll(__ballot(walking));
+            if (n_walking == 0) break;
+            if (n_walking < kBvhKeepActive && n_walking < n_alive) break; // finished lanes wait: go shade / refill them
+            if (walking) bvh_step<R>(A.sc, q, o, d, ud, time, A.tmin, node_tests, sphere_tests);
+        }
+
+        // ---- shade lanes whose query is complete ----
+        if (alive && q.idx >= n_nodes) {
+            nseg++;
+            seg++;
+            bool cont = shade<R>(A.sc, g, o, d, ud, time, q.tbest, q.ibest, thr, acc);
+            if (seg >= A.max_bounces) cont = false;
+            alive = cont;
+            if (cont) {
+                ud = unit(d);
+                bvh_begin<R>(q, d);
+            }
+        }
+    }
+    unsigned long long t0 = nseg, t1 = node_tests, t2 = sphere_tests;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        t0 += __shfl_xor(t0, off);
+        t1 += __shfl_xor(t1, off);
+        t2 += __shfl_xor(t2, off);
+    }
+    if (lane == 0) {
+        atomicAdd(&A.counters[1], t0);
+        atomicAdd(&A.counters[2], t1);
+        atomicAdd(&A.counters[3], t2);
+    }
 }
 
 // ---- pixel = (Σ_chunks partial) · (1/spp), chunk order: src/renderer.zig:94-95 ---------------------

@@ -5,6 +5,7 @@
 // caller's (RCCL through torch.distributed in bench.py).
 #include "../../include/rayz_hip.h"
 #include "rayz_device.hpp"
+#include "bvh_build.hpp"
 
 #include <cmath>
 #include <cstdarg>
@@ -66,8 +67,14 @@ template <class R> struct SceneBuffers {
     r4* sph_pool = nullptr;
     r4* mat = nullptr;
     r4* tex = nullptr;
-    bool ready = false;
+    r4* bvh_nodes = nullptr; // BVH traversal only
+    r4* bvh_sph = nullptr;
+    bool ready = false, bvh_ready = false;
     void release() {
+        (void)hipFree(bvh_nodes);
+        (void)hipFree(bvh_sph);
+        bvh_nodes = bvh_sph = nullptr;
+        bvh_ready = false;
         (void)hipFree(stat);
         (void)hipFree(movy);
         (void)hipFree(movy_vy);
@@ -87,9 +94,13 @@ struct NarrowBuffers {
     d4* movy64 = nullptr;
     d4* movg64 = nullptr;
     uint32_t* slot_pool = nullptr;
+    d4* bvh_sph64 = nullptr; // leaf order (BVH traversal only)
     uint32_t ns_pad = 0, ny_pad = 0, ng_pad = 0;
-    bool ready = false;
+    bool ready = false, bvh_ready = false;
     void release() {
+        (void)hipFree(bvh_sph64);
+        bvh_sph64 = nullptr;
+        bvh_ready = false;
         (void)hipFree(stat64);
         (void)hipFree(movy64);
         (void)hipFree(movg64);
@@ -112,12 +123,14 @@ struct RayzScene {
     SceneBuffers<double> f64;
     NarrowBuffers narrow;
     std::vector<uint32_t> cls[3]; // pool indices by velocity class: static, mov-Y, mov-G (pool order inside)
+    rayz_bvh::FlatBvh bvh;        // host build of the reference's BVH (lazily, first BVH render / export)
+    bool bvh_built = false;
     void* partial = nullptr; // chunk sums, grow-only
     size_t partial_bytes = 0;
     unsigned long long* counters = nullptr; // [0] queue head, [1] segments
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipStream_t last_stream = nullptr;
-    bool rendered = false;
+    bool rendered = false, last_bvh = false;
     RayzRenderStats last{};
 };
 
@@ -233,6 +246,47 @@ template <class R> int upload(RayzScene* s, SceneBuffers<R>& b) {
     return RAYZ_OK;
 }
 
+void ensure_bvh(RayzScene* s) {
+    if (!s->bvh_built) {
+        s->bvh = rayz_bvh::build(s->spheres); // replaces initHittables + bvh.build, src/renderer.zig:76-78
+        s->bvh_built = true;
+    }
+}
+
+template <class R> int upload_bvh(RayzScene* s, SceneBuffers<R>& b) {
+    typedef typename VecOf<R>::type r4;
+    ensure_bvh(s);
+    const rayz_bvh::FlatBvh& t = s->bvh;
+    if (!s->narrow.bvh_ready) {
+        std::vector<d4> sph64;
+        for (uint32_t pool : t.order) {
+            const RayzSphere& q = s->spheres[pool];
+            sph64.push_back(d4{q.center[0], q.center[1], q.center[2], q.radius * q.radius});
+            sph64.push_back(d4{q.velocity[0], q.velocity[1], q.velocity[2], 0.0});
+        }
+        HIP_TRY(put(&s->narrow.bvh_sph64, sph64));
+        s->narrow.bvh_ready = true;
+    }
+    if (b.bvh_ready) return RAYZ_OK;
+    std::vector<r4> nodes, sph;
+    for (const rayz_bvh::FlatNode& n : t.nodes) { // boxes narrowed outward: never smaller than the f64 box
+        nodes.push_back(r4{rayz_bvh::roundDown<R>(n.box.lo[0]), rayz_bvh::roundDown<R>(n.box.lo[1]),
+                           rayz_bvh::roundDown<R>(n.box.lo[2]), Bits<R>::from(n.skip)});
+        nodes.push_back(r4{rayz_bvh::roundUp<R>(n.box.hi[0]), rayz_bvh::roundUp<R>(n.box.hi[1]),
+                           rayz_bvh::roundUp<R>(n.box.hi[2]), Bits<R>::from((n.first << 2) | n.count)});
+    }
+    for (uint32_t pool : t.order) {
+        const RayzSphere& q = s->spheres[pool];
+        const R r = (R)q.radius;
+        sph.push_back(r4{(R)q.center[0], (R)q.center[1], (R)q.center[2], r * r});
+        sph.push_back(r4{(R)q.velocity[0], (R)q.velocity[1], (R)q.velocity[2], Bits<R>::from(pool)});
+    }
+    HIP_TRY(put(&b.bvh_nodes, nodes));
+    HIP_TRY(put(&b.bvh_sph, sph));
+    b.bvh_ready = true;
+    return RAYZ_OK;
+}
+
 int validate_scene(const RayzSceneDesc* d) {
     if (!d) return fail(RAYZ_ERR_BAD_ARG, "scene is null");
     if ((d->n_spheres && !d->spheres) || (d->n_materials && !d->materials) || (d->n_textures && !d->textures))
@@ -286,9 +340,14 @@ int render_impl(RayzScene* s, SceneBuffers<R>& b, const RayzCameraDesc* cam, con
                 hipStream_t stream) {
     typedef typename VecOf<R>::type r4;
     if (g_device < 0) return fail(RAYZ_ERR_NO_DEVICE, "rayz_hip_init has not succeeded");
-    if (p->traversal != RAYZ_TRAVERSAL_LINEAR) return fail(RAYZ_ERR_BAD_ARG, "BVH traversal is not built yet");
+    const bool use_bvh = p->traversal == RAYZ_TRAVERSAL_BVH;
+    if (use_bvh && s->spheres.size() >= (1u << 30)) return fail(RAYZ_ERR_BAD_ARG, "too many spheres for the BVH layout");
     int rc = upload<R>(s, b);
     if (rc != RAYZ_OK) return rc;
+    if (use_bvh) {
+        rc = upload_bvh<R>(s, b);
+        if (rc != RAYZ_OK) return rc;
+    }
 
     const uint32_t rows = rayz_hip_shard_rows(p);
     const uint64_t shard_pixels64 = (uint64_t)rows * p->width;
@@ -300,6 +359,7 @@ int render_impl(RayzScene* s, SceneBuffers<R>& b, const RayzCameraDesc* cam, con
     s->last = RayzRenderStats{};
     s->last.primary_rays = shard_pixels64 * p->samples_per_px;
     s->last_stream = stream;
+    s->last_bvh = use_bvh;
     if (items64 == 0) {
         s->rendered = false;
         return RAYZ_OK;
@@ -341,6 +401,10 @@ int render_impl(RayzScene* s, SceneBuffers<R>& b, const RayzCameraDesc* cam, con
     A.sc.ny_pad = s->narrow.ny_pad;
     A.sc.ng_pad = s->narrow.ng_pad;
     A.sc.n_spheres = (uint32_t)s->spheres.size();
+    A.sc.bvh_nodes = b.bvh_nodes;
+    A.sc.bvh_sph = b.bvh_sph;
+    A.sc.bvh_sph64 = s->narrow.bvh_sph64;
+    A.sc.bvh_n_nodes = use_bvh ? (uint32_t)s->bvh.nodes.size() : 0u;
     fill_camera<R>(cam, A.cam);
     A.partial = (r4*)s->partial;
     A.counters = s->counters;
@@ -359,7 +423,8 @@ int render_impl(RayzScene* s, SceneBuffers<R>& b, const RayzCameraDesc* cam, con
     A.total_items = (uint32_t)items64;
 
     int blocks_per_cu = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, trace_kernel<R>, 256, 0));
+    if (use_bvh) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, trace_kernel_bvh<R>, 256, 0));
+    else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, trace_kernel<R>, 256, 0));
     if (blocks_per_cu < 1) blocks_per_cu = 1;
     uint64_t grid = (uint64_t)g_num_cu * blocks_per_cu;
     const uint64_t want = (items64 + 255) / 256;
@@ -367,7 +432,8 @@ int render_impl(RayzScene* s, SceneBuffers<R>& b, const RayzCameraDesc* cam, con
 
     HIP_TRY(hipMemsetAsync(s->counters, 0, 4 * sizeof(unsigned long long), stream));
     HIP_TRY(hipEventRecord(s->ev0, stream));
-    hipLaunchKernelGGL(trace_kernel<R>, dim3((uint32_t)grid), dim3(256), 0, stream, A);
+    if (use_bvh) hipLaunchKernelGGL(trace_kernel_bvh<R>, dim3((uint32_t)grid), dim3(256), 0, stream, A);
+    else hipLaunchKernelGGL(trace_kernel<R>, dim3((uint32_t)grid), dim3(256), 0, stream, A);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev1, stream));
     hipLaunchKernelGGL(resolve_kernel<R>, dim3((A.shard_pixels + 255) / 256), dim3(256), 0, stream,
@@ -525,11 +591,33 @@ int rayz_hip_scene_sync(RayzScene* s, RayzRenderStats* stats) {
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
         s->last.segments = c[1];
-        s->last.sphere_tests = c[1] * (unsigned long long)s->spheres.size();
-        s->last.node_tests = 0;
+        s->last.sphere_tests = s->last_bvh ? c[3] : c[1] * (unsigned long long)s->spheres.size();
+        s->last.node_tests = s->last_bvh ? c[2] : 0;
         s->last.kernel_ms = ms;
     }
     if (stats) *stats = s->last;
+    return RAYZ_OK;
+}
+
+int rayz_hip_scene_bvh(RayzScene* s, uint32_t* n_nodes, uint32_t* depth, double* boxes, uint32_t* skip, uint32_t* first,
+                       uint32_t* count, uint32_t* order) {
+    if (!s || !n_nodes) return fail(RAYZ_ERR_BAD_ARG, "null argument");
+    try {
+        ensure_bvh(s);
+    } catch (...) {
+        return fail(RAYZ_ERR_OOM, "host allocation failed");
+    }
+    const rayz_bvh::FlatBvh& t = s->bvh;
+    *n_nodes = (uint32_t)t.nodes.size();
+    if (depth) *depth = t.depth;
+    for (size_t i = 0; i < t.nodes.size(); ++i) {
+        if (boxes)
+            for (int k = 0; k < 3; ++k) boxes[6 * i + k] = t.nodes[i].box.lo[k], boxes[6 * i + 3 + k] = t.nodes[i].box.hi[k];
+        if (skip) skip[i] = t.nodes[i].skip;
+        if (first) first[i] = t.nodes[i].first;
+        if (count) count[i] = t.nodes[i].count;
+    }
+    if (order) std::copy(t.order.begin(), t.order.end(), order);
     return RAYZ_OK;
 }
 

@@ -1,0 +1,196 @@
+"""The reference's accelerator (src/hit.zig:44-217) as the product builds and traverses it.
+
+CPU part: the product's host builder (rayz_amd/csrc/bvh_build.hpp, through rayz_hip_scene_bvh) against the
+oracle's independent mode-A build, structural invariants, and the oracle's own BVH-vs-flat-list agreement.
+GPU part (marked): the HIP traversal against the oracle's mode B with BVH traversal, bit for bit."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import assert_images_equal
+from rayz_amd import capi, tracer
+
+_P = C.POINTER
+
+
+def product_tree(t):
+    lib = capi.load()
+    sd = t.scene_desc()
+    h = C.c_void_p()
+    assert lib.rayz_hip_scene_create(C.byref(sd), C.byref(h)) == capi.OK
+    n, depth = C.c_uint32(), C.c_uint32()
+    assert lib.rayz_hip_scene_bvh(h, C.byref(n), C.byref(depth), None, None, None, None, None) == capi.OK
+    N = n.value
+    boxes = np.zeros((N, 6))
+    skip, first, count = (np.zeros(N, np.uint32) for _ in range(3))
+    order = np.zeros(sd.n_spheres, np.uint32)
+    assert lib.rayz_hip_scene_bvh(h, C.byref(n), None, boxes.ctypes.data_as(_P(C.c_double)),
+                                  skip.ctypes.data_as(_P(C.c_uint32)), first.ctypes.data_as(_P(C.c_uint32)),
+                                  count.ctypes.data_as(_P(C.c_uint32)), order.ctypes.data_as(_P(C.c_uint32))) == capi.OK
+    lib.rayz_hip_scene_destroy(h)
+    return dict(n=N, depth=depth.value, boxes=boxes, skip=skip, first=first, count=count, order=order)
+
+
+def oracle_tree(oracle, t):
+    lib = oracle.load()
+    sd = t.scene_desc()
+    N = lib.rayz_oracle_bvh_flat(C.byref(sd), None, None, None, None, None)
+    boxes = np.zeros((N, 6))
+    skip, first, count = (np.zeros(N, np.uint32) for _ in range(3))
+    order = np.zeros(sd.n_spheres, np.uint32)
+    lib.rayz_oracle_bvh_flat(C.byref(sd), boxes.ctypes.data_as(_P(C.c_double)), skip.ctypes.data_as(_P(C.c_uint32)),
+                             first.ctypes.data_as(_P(C.c_uint32)), count.ctypes.data_as(_P(C.c_uint32)),
+                             order.ctypes.data_as(_P(C.c_uint32)))
+    return dict(n=N, boxes=boxes, skip=skip, first=first, count=count, order=order)
+
+
+def _scenes():
+    yield "randomBouncing", tracer.randomBouncing(64, seed=42)
+    yield "grid3", tracer.randomBouncing(64, -3, 3, seed=5)
+    yield "10k", tracer.randomBouncing(64, -50, 50, seed=42)
+    yield "three", tracer.threeSpheres(64, seed=1)
+    t = tracer.Tracer.init(64, 20, 1, 0, (0, 0, 3), (0, 0, 0), (0, 1, 0), seed=1)
+    tx = t.pool.add_solid_texture((0.5, 0.5, 0.5))
+    m = t.pool.add_diffuse(tx)
+    t.pool.add_sphere((0, 0, 0), 1.0, m)
+    yield "one", t
+    t = tracer.Tracer.init(64, 20, 1, 0, (0, 0, 3), (0, 0, 0), (0, 1, 0), seed=1)
+    tx = t.pool.add_solid_texture((0.5, 0.5, 0.5))
+    m = t.pool.add_diffuse(tx)
+    for k in range(7):  # equal keys on every axis: exercises the STABLE sort (std.mem.sort)
+        t.pool.add_sphere((0, 0, 0), 0.5 + 0.0 * k, m)
+    yield "coincident", t
+
+
+@pytest.mark.parametrize("name", ["randomBouncing", "grid3", "10k", "three", "one", "coincident"])
+def test_product_builder_equals_oracle_build(built, oracle, name):
+    t = dict(_scenes())[name]
+    a, b = product_tree(t), oracle_tree(oracle, t)
+    assert a["n"] == b["n"]
+    for k in ("boxes", "skip", "first", "count", "order"):
+        assert np.array_equal(a[k], b[k]), k
+
+
+def test_sphere_bbox_and_enclose_through_the_builder(built):
+    """The reference's "sphere bbox" (src/geom.zig:69-84) and "enclose bbox" (src/hit.zig:237-245) vectors."""
+    t = tracer.Tracer.init(64, 20, 1, 0, (0, 0, 3), (0, 0, 0), (0, 1, 0), seed=1)
+    m = t.pool.add_dielectric(1.5)
+    t.pool.add_sphere((0, 0, 0), 1.0, m)  # stationary unit sphere: [-1, 1]
+    tr = product_tree(t)
+    assert tr["n"] == 1 and tr["boxes"][0].tolist() == [-1, -1, -1, 1, 1, 1]
+    t.pool.add_sphere((0, 0, 0), 1.0, m, velocity=(1, 1, 1))  # moving (0 -> 1): [-1, 2]
+    tr = product_tree(t)
+    assert tr["n"] == 1 and tr["count"][0] == 2
+    assert tr["boxes"][0].tolist() == [-1, -1, -1, 2, 2, 2]  # union of the two boxes = enclose
+
+
+def test_tree_invariants(built):
+    t = tracer.randomBouncing(64, -20, 20, seed=3)
+    tr = product_tree(t)
+    N, ns = tr["n"], t.info().n_spheres
+    leaves = tr["count"] > 0
+    assert tr["count"].max() <= 2 and tr["count"][leaves].sum() == ns  # leaves of <= 2 own every hittable once
+    assert N == 2 * leaves.sum() - 1
+    assert sorted(tr["order"].tolist()) == list(range(ns))
+    assert tr["skip"][0] == N and (tr["skip"] > np.arange(N)).all()
+    # pre-order: an inner node's left child is the next node, its right child is the left child's skip
+    for i in np.flatnonzero(~leaves)[:500]:
+        l = i + 1
+        r = tr["skip"][l]
+        assert r < tr["skip"][i] and tr["skip"][r] == tr["skip"][i]
+        for c in (l, r):  # children inside the parent box
+            assert (tr["boxes"][c][:3] >= tr["boxes"][i][:3]).all() and (tr["boxes"][c][3:] <= tr["boxes"][i][3:]).all()
+    assert 10 <= tr["depth"] <= 16  # median split: ceil(log2(n/2)) + 1
+
+
+def test_oracle_bvh_traversal_equals_flat_list(oracle):
+    """Mode B: the skip-link walk finds the same nearest hits as the flat list (same image, same segments) while
+    testing ~37 boxes + ~5 spheres per segment instead of every sphere."""
+    t = tracer.randomBouncing(96, seed=42)
+    t.samples_per_px = 8
+    t.set_gpu(render_seed=3)
+    sd, cam = t.scene_desc(), t.camera_desc()
+    flat, sf = oracle.render_b(sd, cam, t.params())
+    t.set_gpu(traversal=capi.TRAVERSAL_BVH)
+    bvh, sb = oracle.render_b(sd, cam, t.params())
+    assert np.array_equal(flat, bvh) and sf.segments == sb.segments
+    assert sf.sphere_tests == sf.segments * sd.n_spheres and sf.node_tests == 0
+    assert 25 < sb.node_tests / sb.segments < 50 and 3 < sb.sphere_tests / sb.segments < 8
+    # and mode A's recursive traversal visits a comparable number of boxes (same tree, f64, first-hit order)
+    pa = t.params()
+    pa.precision, pa.tmin = capi.PRECISION_F64, 1e-10
+    rs = t.rng_state().copy()
+    _, sa = oracle.render_a(sd, cam, pa, rs)
+    assert abs(sa.node_tests / sa.segments - sb.node_tests / sb.segments) < 2.0
+
+
+# ---- GPU ----------------------------------------------------------------------------------------------
+def _pair(gpu, oracle, t):
+    scene, cam, p = t.scene_desc(), t.camera_desc(), t.params()
+    got, gst = gpu.render_host(scene, cam, p)
+    want, ost = oracle.render_b(scene, cam, p)
+    return got, want, gst, ost
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", [capi.PRECISION_F32, capi.PRECISION_F64])
+def test_gpu_bvh_parity_random_bouncing(gpu, oracle, prec):
+    t = tracer.randomBouncing(160, seed=42)
+    t.samples_per_px = 16
+    t.set_gpu(render_seed=5, traversal=capi.TRAVERSAL_BVH, precision=prec)
+    got, want, gst, ost = _pair(gpu, oracle, t)
+    assert_images_equal(got, want, f"BVH randomBouncing precision {prec}")
+    assert (gst.segments, gst.node_tests, gst.sphere_tests) == (ost.segments, ost.node_tests, ost.sphere_tests)
+
+
+@pytest.mark.gpu
+def test_gpu_bvh_parity_10k_and_equals_flat_list(gpu, oracle):
+    t = tracer.randomBouncing(128, -50, 50, seed=42)
+    t.samples_per_px = 8
+    t.set_gpu(render_seed=1, traversal=capi.TRAVERSAL_BVH)
+    got, want, gst, ost = _pair(gpu, oracle, t)
+    assert_images_equal(got, want, "BVH 10k spheres")
+    assert (gst.segments, gst.node_tests, gst.sphere_tests) == (ost.segments, ost.node_tests, ost.sphere_tests)
+    t.set_gpu(traversal=capi.TRAVERSAL_LINEAR)
+    flat, fst = gpu.render_host(t.scene_desc(), t.camera_desc(), t.params())
+    # same nearest hits up to measure-zero grazing cases of the box test: allow a handful of differing pixels
+    assert (np.abs(flat - got).max(axis=2) > 0).mean() < 1e-3
+    assert abs(int(fst.segments) - int(gst.segments)) <= 1e-4 * fst.segments
+
+
+@pytest.mark.gpu
+def test_gpu_bvh_edge_cases(gpu, oracle):
+    for name in ("one", "coincident", "three"):
+        t = dict(_scenes())[name]
+        t.samples_per_px, t.max_bounces = 4, 6
+        t.set_gpu(render_seed=2, traversal=capi.TRAVERSAL_BVH)
+        got, want, gst, ost = _pair(gpu, oracle, t)
+        assert_images_equal(got, want, f"BVH {name}")
+        assert gst.node_tests == ost.node_tests
+    # empty pool: no tree at all, background only
+    t = tracer.Tracer.init(48, 40.0, 1.0, 0.0, (0, 0, 0), (0, 0.3, -1), (0, 1, 0), seed=1)
+    t.samples_per_px = 2
+    t.set_gpu(render_seed=2, traversal=capi.TRAVERSAL_BVH)
+    got, want, gst, _ = _pair(gpu, oracle, t)
+    assert_images_equal(got, want, "BVH empty scene")
+    assert gst.node_tests == 0 and gst.segments == gst.primary_rays
+
+
+@pytest.mark.gpu
+def test_gpu_bvh_shards_and_custom_scene(gpu, oracle):
+    from test_gpu_parity import _custom_scene
+
+    t = _custom_scene()
+    t.samples_per_px, t.max_bounces = 12, 20
+    t.set_gpu(render_seed=9, traversal=capi.TRAVERSAL_BVH)
+    got, want, gst, ost = _pair(gpu, oracle, t)
+    assert_images_equal(got, want, "BVH custom scene")
+    scene, cam, p = t.scene_desc(), t.camera_desc(), t.params()
+    out = np.zeros_like(got)
+    for idx in range(3):
+        q = t.params()
+        q.tile_rows, q.shard_index, q.shard_count = 4, idx, 3
+        part, _ = gpu.render_host(scene, cam, q)
+        out[gpu.shard_row_indices(p.height, 4, idx, 3)] = part
+    assert_images_equal(out, got, "BVH 3 shards")
