@@ -44,6 +44,7 @@ def parse_args():
     ap.add_argument("--traversal", choices=["linear", "bvh"], default="linear")
     ap.add_argument("--precision", choices=["f32", "f64"], default="f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the extra BVH-traversal frame reported beside the headline")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     return ap.parse_args()
 
@@ -156,18 +157,58 @@ def main():
         frame_segments = float(np.mean(seg_total))
         kernel_ms_avg = float(np.mean(kernel_ms))
 
+    # N = 1 only, after the timed region: the same frame through the reference's own accelerator (BVH traversal),
+    # reported beside the headline (which stays the flat hit list BASELINE.json names)
+    also = None
+    if world == 1 and args.traversal == "linear" and not args.no_also:
+        t.set_gpu(traversal=capi.TRAVERSAL_BVH)
+        pb = rdist.shard_params(t.params(), rank, world)
+        dscene.render_into(cam, pb, fg.tile.data_ptr(), stream)
+        dscene.sync()
+        t1 = time.perf_counter()
+        dscene.render_into(cam, pb, fg.tile.data_ptr(), stream)
+        stb = dscene.sync()
+        dtb = time.perf_counter() - t1
+        also = {"bvh_traversal": {"value": H * W * args.spp / dtb / 1e6, "unit": "Msamples/s", "ms_per_step": dtb * 1e3,
+                                  "kernel_ms": stb.kernel_ms, "node_tests_per_segment": stb.node_tests / max(stb.segments, 1),
+                                  "sphere_tests_per_segment": stb.sphere_tests / max(stb.segments, 1)}}
+        t.set_gpu(traversal=capi.TRAVERSAL_LINEAR)
+
     if rank == 0:
         samples_per_step = H * W * args.spp
         info = t.info()
         sd = scene
         n_moving = sum(1 for i in range(sd.n_spheres) if any(sd.spheres[i].velocity[k] != 0 for k in range(3)))
         n_static = sd.n_spheres - n_moving
-        # roofline of the dominant kernel (trace_kernel): algorithmic flops of the reject test per launch.
-        # With N GPUs each launch covers 1/N of the frame; quote rank-mean flops over the slowest rank's time.
-        flops = frame_segments / world * (n_static * FLOP_PER_TEST_STATIC + n_moving * FLOP_PER_TEST_MOVING)
-        achieved = flops / (kernel_ms_avg * 1e-3) / 1e12
         chunks = (args.spp + 15) // 16
         hbm_bytes = (H * W / world) * (chunks * 16 * 2 + 12) + 8 * (n_static * 16 + n_moving * 32) * 2.5
+        if args.traversal == "linear":
+            # roofline of the dominant kernel (trace_kernel): algorithmic flops of the reject test per launch.
+            # With N GPUs each launch covers 1/N of the frame; rank-mean flops over the slowest rank's time.
+            flops = frame_segments / world * (n_static * FLOP_PER_TEST_STATIC + n_moving * FLOP_PER_TEST_MOVING)
+            kernel = "trace_kernel<%s>" % ("double" if args.precision == "f64" else "float")
+            note = ("VALU-bound, not HBM/MFMA (SURVEY.md 8d): algorithmic flops = segments x (18 x static + 24 x moving "
+                    "spheres); the scene (320 KB) is L2/scalar-cache resident")
+        else:
+            st_last = dscene.sync()
+            # slab test: 6 sub + 6 mul + 6 min/max + 2 three-way min/max + slack mul = 21 flop; leaf sphere test 24
+            flops = (st_last.node_tests * 21 + st_last.sphere_tests * FLOP_PER_TEST_MOVING)
+            kernel = "trace_kernel_bvh<%s>" % ("double" if args.precision == "f64" else "float")
+            note = ("per-lane tree walk: divergence- and latency-bound, priced against the same FP32 vector peak; "
+                    "algorithmic flops = 21 x box tests + 24 x leaf sphere tests")
+        achieved = flops / (kernel_ms_avg * 1e-3) / 1e12
+        peak = PEAK_VALU_F32_TFLOPS / (2.0 if args.precision == "f64" else 1.0)
+        # HBM bytes per launch from the committed PMC passes of this very command (profiles/), when they exist:
+        # FETCH_SIZE doubled (gfx950 wide-read correction, MI355X_MICROARCH.md) + WRITE_SIZE, KiB -> bytes
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01", "r01_pmc_summary.json")
+        if (os.path.exists(pmc) and world == 1 and args.traversal == "linear" and args.precision == "f32"
+                and (args.width, args.spp, args.grid) == (1920, 1024, 50)):
+            try:
+                z = json.load(open(pmc))
+                traffic = (2 * z["r01_pmc_fetch"]["FETCH_SIZE"] + z["r01_pmc_write"]["WRITE_SIZE"]) * 1024
+            except Exception:
+                traffic = None
         out = {
             "metric": "Msamples/sec, 10k-sphere 1920x1080x1024spp (flat hit list)",
             "value": samples_per_step * args.steps / elapsed / 1e6,
@@ -185,15 +226,17 @@ def main():
                 "segments_per_sample": frame_segments / samples_per_step,
             },
             "roofline": {
-                "bound": "valu_fp32", "achieved": achieved, "peak": PEAK_VALU_F32_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_VALU_F32_TFLOPS, "traffic": None,
-                "kernel": "trace_kernel<float>", "kernel_ms": kernel_ms_avg,
-                "note": "VALU-bound, not HBM/MFMA (SURVEY.md §8d): algorithmic flops = segments x "
-                        "(18 x static + 24 x moving spheres); the scene (320 KB) is L2/scalar-cache resident",
+                "bound": "valu_fp32" if args.precision == "f32" else "valu_fp64", "achieved": achieved, "peak": peak,
+                "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+                "kernel": kernel, "kernel_ms": kernel_ms_avg, "note": note,
                 "hbm": {"algorithmic_bytes": hbm_bytes, "achieved": hbm_bytes / (kernel_ms_avg * 1e-3) / 1e9,
+                        "measured_bytes": traffic,
+                        "measured": None if traffic is None else traffic / (kernel_ms_avg * 1e-3) / 1e9,
                         "peak": PEAK_HBM_GBPS, "unit": "GB/s"},
             },
         }
+        if also:
+            out["also"] = also
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(t, args.cpu_seconds)
         print(json.dumps(out), flush=True)
