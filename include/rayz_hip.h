@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RAYZ_HIP_ABI_VERSION 1u
+#define RAYZ_HIP_ABI_VERSION 2u
 
 typedef enum RayzStatus {
     RAYZ_OK = 0,
@@ -92,7 +92,21 @@ typedef struct RayzSphere {
     uint32_t _pad;
 } RayzSphere;
 
-/* The three `MemPool` lists (src/ecs.zig:22-27), borrowed for the duration of the call. */
+/* A triangle hittable.  BUILD-DEFINED: the reference's geom.zig holds only `Sphere` (src/geom.zig:11-67);
+ * BASELINE.json's config 5 asks for a triangle path, so this primitive is fitted to the `Hittable` / `Hit`
+ * contract (src/hit.zig:8-42): two-sided, nearest root in [tmin, tmax], geometric normal flipped to face the
+ * ray by `Hit.init`, stationary.  Its results are parity-unpinned (no reference code or test exists). */
+typedef struct RayzTriangle {
+    double v0[3];
+    double v1[3];
+    double v2[3];
+    uint32_t material; /* MaterialHandle.idx */
+    uint32_t _pad;
+} RayzTriangle;
+
+/* The `MemPool` lists (src/ecs.zig:22-27) plus the build-defined triangle list, borrowed for the duration of
+ * the call.  Hittables are numbered spheres first, then triangles (the order `initHittables` would append
+ * them, src/ecs.zig:43-51). */
 typedef struct RayzSceneDesc {
     const RayzSphere* spheres;
     const RayzMaterial* materials;
@@ -100,7 +114,8 @@ typedef struct RayzSceneDesc {
     uint32_t n_spheres;
     uint32_t n_materials;
     uint32_t n_textures;
-    uint32_t _pad;
+    uint32_t n_triangles;
+    const RayzTriangle* triangles;
 } RayzSceneDesc;
 
 /* The fields of `Camera` AFTER `Camera.init` (src/camera.zig:9-16): results, not look-at params. */
@@ -138,7 +153,7 @@ typedef struct RayzRenderParams {
 typedef struct RayzRenderStats {
     uint64_t primary_rays; /* rows_in_shard * width * samples_per_px */
     uint64_t segments;     /* findHit calls: one per ray segment, src/renderer.zig:107 */
-    uint64_t sphere_tests; /* Sphere.hitInner evaluations, src/geom.zig:38-66 */
+    uint64_t sphere_tests; /* primitive tests: Sphere.hitInner evaluations (src/geom.zig:38-66) + triangle tests */
     uint64_t node_tests;   /* AABB.hit evaluations (BVH traversal only), src/hit.zig:70-98 */
     double kernel_ms;      /* HIP-event time of the trace kernel(s) of the last render on this scene */
 } RayzRenderStats;
@@ -163,7 +178,7 @@ int rayz_hip_scene_destroy(RayzScene* scene);
 /* The BVH `render()` would build (src/renderer.zig:76-78 -> src/hit.zig:130-161), flattened in depth-first
  * pre-order with skip links as the GPU traverses it.  Host only (no device needed).  Call once with every array
  * NULL to get *n_nodes, then with arrays of n_nodes (boxes: 6 doubles per node, lo then hi; skip/first/count:
- * one u32 per node; order: n_spheres pool indices in leaf order).  count == 0 marks an inner node. */
+ * one u32 per node; order: n_spheres + n_triangles hittable indices in leaf order).  count == 0 marks an inner node. */
 int rayz_hip_scene_bvh(RayzScene* scene, uint32_t* n_nodes, uint32_t* depth, double* boxes, uint32_t* skip,
                        uint32_t* first, uint32_t* count, uint32_t* order);
 

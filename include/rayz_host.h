@@ -30,7 +30,7 @@ typedef enum RayzTracerField {
 typedef struct RayzTracerInfo {
     uint32_t width, height;
     uint32_t samples_per_px, max_bounces;
-    uint32_t n_spheres, n_materials, n_textures, _pad;
+    uint32_t n_spheres, n_materials, n_textures, n_triangles;
 } RayzTracerInfo;
 
 /* Tracer.init, src/renderer.zig:29-64.  has_seed == 0 seeds the Tracer's DefaultPrng from the OS as the
@@ -47,6 +47,9 @@ int64_t rayz_tracer_add_material_metallic(RayzTracer* t, uint32_t texture, doubl
 int64_t rayz_tracer_add_material_dielectric(RayzTracer* t, double refractive_index);
 int64_t rayz_tracer_add_sphere(RayzTracer* t, const double* center, const double* velocity, double radius,
                                uint32_t material);
+
+/* build-defined triangle hittable (see RayzTriangle) */
+int64_t rayz_tracer_add_triangle(RayzTracer* t, const double* v0, const double* v1, const double* v2, uint32_t material);
 
 int rayz_tracer_set_u64(RayzTracer* t, int field, uint64_t value);
 int rayz_tracer_set_f64(RayzTracer* t, int field, double value);
@@ -82,6 +85,8 @@ void rayz_image_to_u8(const double* rgb, size_t n_pixels, uint8_t* out);
 int rayz_scene_random_bouncing(uint32_t img_w, int grid_lo, int grid_hi, int has_seed, uint64_t seed,
                                RayzTracer** out);
 int rayz_scene_three_spheres(uint32_t img_w, int has_seed, uint64_t seed, RayzTracer** out);
+/* BASELINE config 5 (build-defined): n x n-quad height field = 2 n^2 triangles + three spheres. */
+int rayz_scene_triangle_mesh(uint32_t img_w, uint32_t n, int has_seed, uint64_t seed, RayzTracer** out);
 
 #ifdef __cplusplus
 }

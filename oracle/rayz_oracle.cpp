@@ -269,9 +269,35 @@ struct Sphere {                                                              // 
     }
 };
 
+// BUILD-DEFINED triangle hittable (the reference has spheres only): Möller–Trumbore, two-sided, nearest root in
+// [tmin, tmax], geometric normal handed to Hit.init.  Its box is padded by 1e-4 per side: AABB.hit's strict
+// `t1 > t0` (src/hit.zig:97) would never hit the flat box of an axis-aligned triangle.
+struct Triangle {
+    V3 v0, v1, v2;
+    u32 material;
+    AABB boundingBox() const {
+        const V3 pad = V3::of(1e-4);
+        return AABB{v0.vmin(v1).vmin(v2).sub(pad), v0.vmax(v1).vmax(v2).add(pad)};
+    }
+    Hit hitInner(const Ray& ray, double tmin, double tmax) const {
+        const V3 e1 = v1.sub(v0), e2 = v2.sub(v0);
+        const V3 p = ray.dir.cross(e2);
+        const double det = e1.dot(p);
+        if (det == 0) return Hit{};
+        const V3 s = ray.origin.sub(v0);
+        const double u = s.dot(p) / det;
+        const V3 q = s.cross(e1);
+        const double v = ray.dir.dot(q) / det;
+        if (u < 0 || v < 0 || u + v > 1) return Hit{};
+        const double t = e2.dot(q) / det;
+        if (!(t >= tmin && t <= tmax)) return Hit{};
+        return Hit::init(ray, ray.at(t), e1.cross(e2).unit(), t, material);
+    }
+};
+
 struct Hittable {                                                            // src/hit.zig:8-12
     AABB bbox;
-    u32 sphere;
+    u32 sphere; // hittable index: spheres first, then triangles (index - n_spheres)
 };
 
 struct Counters {
@@ -280,6 +306,11 @@ struct Counters {
 
 struct Scene {
     std::vector<Sphere> spheres;
+    std::vector<Triangle> triangles;
+    Hit hitPrim(u32 i, const Ray& ray, double tmin, double tmax) const {
+        return i < spheres.size() ? spheres[i].hitInner(ray, tmin, tmax)
+                                  : triangles[i - spheres.size()].hitInner(ray, tmin, tmax);
+    }
     std::vector<RayzMaterial> materials;
     std::vector<RayzTexture> textures;
     std::vector<Hittable> hittables;
@@ -331,7 +362,7 @@ struct BVH {                                                                 // 
         for (size_t i = n.starti; i < n.endi; ++i) {
             const double maxt = maybe.valid ? maybe.t : tmax;
             c.sphere_tests++;
-            const Hit nh = sc.spheres[sc.hittables[i].sphere].hitInner(ray, tmin, maxt);
+            const Hit nh = sc.hitPrim(sc.hittables[i].sphere, ray, tmin, maxt);
             if (nh.valid) maybe = nh;
         }
         return maybe;
@@ -516,7 +547,7 @@ struct Tracer {                                                              // 
         for (size_t i = 0; i < sc.hittables.size(); ++i) {
             const double maxt = maybe.valid ? maybe.t : inf;
             cnt.sphere_tests++;
-            const Hit nh = sc.spheres[sc.hittables[i].sphere].hitInner(ray, tmin, maxt);
+            const Hit nh = sc.hitPrim(sc.hittables[i].sphere, ray, tmin, maxt);
             if (nh.valid) maybe = nh;
         }
         return maybe;
@@ -581,7 +612,12 @@ template <class R> struct Sph {
     u32 mat;
     u32 pool; // index in MemPool.spheres
 };
+template <class R> struct Tri { // build-defined triangle: v0, e1 = v1 - v0, e2 = v2 - v0 (subtracted in f64, narrowed)
+    V<R> v0, e1, e2;
+    u32 mat;
+};
 template <class R> struct SceneB {
+    std::vector<Tri<R>> tri; // hittable index = n_spheres + position
     std::vector<Sph<R>> sph; // scan order (any: the result does not depend on it); here static, then moving
     std::vector<u32> by_pool; // pool index → position in sph
     u32 n_static = 0;
@@ -625,6 +661,18 @@ template <class R> static SceneB<R> buildScene(const RayzSceneDesc& d) {
     }
     s.by_pool.resize(s.sph.size());
     for (u32 k = 0; k < s.sph.size(); ++k) s.by_pool[s.sph[k].pool] = k;
+    for (u32 i = 0; i < d.n_triangles; ++i) {
+        const RayzTriangle& q = d.triangles[i];
+        Tri<R> o;
+        o.v0 = narrow3<R>(q.v0);
+        for (int pass = 0; pass < 2; ++pass) {
+            const double* w = pass ? q.v2 : q.v1;
+            const V<R> e{(R)(w[0] - q.v0[0]), (R)(w[1] - q.v0[1]), (R)(w[2] - q.v0[2])};
+            (pass ? o.e2 : o.e1) = e;
+        }
+        o.mat = q.material;
+        s.tri.push_back(o);
+    }
     for (u32 i = 0; i < d.n_materials; ++i) {
         const RayzMaterial& m = d.materials[i];
         Mat<R> o;
@@ -666,19 +714,22 @@ static u32 subtreeEnd(const A::BVH& t, int ni) {
 }
 
 template <class R> static void buildBvh(const RayzSceneDesc& d, SceneB<R>& s) {
-    if (d.n_spheres == 0) return;
-    A::Scene sa;
+    if (d.n_spheres + d.n_triangles == 0) return;
+    std::vector<A::Hittable> hs;
     for (u32 i = 0; i < d.n_spheres; ++i) {
         A::Sphere q;
         q.center.origin = A::v3(d.spheres[i].center);
         q.center.dir = A::v3(d.spheres[i].velocity);
         q.radius = d.spheres[i].radius;
-        q.material = d.spheres[i].material;
-        sa.spheres.push_back(q);
+        hs.push_back({q.boundingBox(), i});
     }
-    for (u32 i = 0; i < d.n_spheres; ++i) sa.hittables.push_back({sa.spheres[i].boundingBox(), i});
+    for (u32 i = 0; i < d.n_triangles; ++i) {
+        A::Triangle t;
+        t.v0 = A::v3(d.triangles[i].v0), t.v1 = A::v3(d.triangles[i].v1), t.v2 = A::v3(d.triangles[i].v2);
+        hs.push_back({t.boundingBox(), d.n_spheres + i});
+    }
     A::BVH t;
-    t.build(sa.hittables, 0, sa.hittables.size());
+    t.build(hs, 0, hs.size());
     for (size_t i = 0; i < t.nodes.size(); ++i) {
         const A::BVH::Node& n = t.nodes[i];
         typename SceneB<R>::Node o;
@@ -688,7 +739,11 @@ template <class R> static void buildBvh(const RayzSceneDesc& d, SceneB<R>& s) {
         o.count = n.left < 0 ? (u32)(n.endi - n.starti) : 0;
         s.nodes.push_back(o);
     }
-    for (const A::Hittable& h : sa.hittables) s.leaf_order.push_back(h.sphere);
+    for (const A::Hittable& h : hs) s.leaf_order.push_back(h.sphere);
+}
+
+template <class R> static V<R> cross3(V<R> a, V<R> b) {
+    return {fm(a.y, b.z, -(a.z * b.y)), fm(a.z, b.x, -(a.x * b.z)), fm(a.x, b.y, -(a.y * b.x))};
 }
 
 template <class R> static CamB<R> buildCamera(const RayzCameraDesc& d) {
@@ -814,6 +869,24 @@ static PathResult<R> tracePath(const SceneB<R>& sc, const CamB<R>& cam, const Ra
                 ibest = (int)q.pool;
             }
         };
+        // one triangle (build-defined): Möller–Trumbore in R; sign-free barycentric filter, then t = (e2·q) / det
+        const u32 n_sph = (u32)sc.sph.size();
+        auto testTriangle = [&](const Tri<R>& q, u32 prim) {
+            const V<R> pv = cross3(d, q.e2);
+            const R det = dot3(q.e1, pv);
+            const V<R> sv{o.x - q.v0.x, o.y - q.v0.y, o.z - q.v0.z};
+            const R su = dot3(sv, pv) * det;
+            const V<R> qv = cross3(sv, q.e1);
+            const R svv = dot3(d, qv) * det;
+            const R w = fm(det, det, -(su + svv));
+            if (!(std::fmin(std::fmin(su, svv), w) >= R(0))) return;
+            if (det == R(0)) return;
+            const R t = dot3(q.e2, qv) / det;
+            if (t >= tmin && (t < tbest || (t == tbest && (int)prim > ibest))) {
+                tbest = t;
+                ibest = (int)prim;
+            }
+        };
         if (p.traversal == RAYZ_TRAVERSAL_BVH) {
             // src/hit.zig:181-216 as a skip-link walk; slab test src/hit.zig:70-98 with 1/d hoisted and a
             // 4-ulp slack (never culls a box the f64 narrow phase would hit)
@@ -834,15 +907,17 @@ static PathResult<R> tracePath(const SceneB<R>& sc, const CamB<R>& cam, const Ra
                     if (nd.count == 0) next = idx + 1;
                     for (u32 k = 0; k < nd.count; ++k) {
                         res.sphere_tests++;
-                        testSphere(sc.sph[sc.by_pool[sc.leaf_order[nd.first + k]]]);
+                        const u32 prim = sc.leaf_order[nd.first + k];
+                        if (prim < n_sph) testSphere(sc.sph[sc.by_pool[prim]]);
+                        else testTriangle(sc.tri[prim - n_sph], prim);
                     }
                 }
                 idx = next;
             }
         } else {
-            const u32 n = (u32)sc.sph.size();
-            res.sphere_tests += n;
-            for (u32 i = 0; i < n; ++i) testSphere(sc.sph[i]);
+            res.sphere_tests += n_sph + (u32)sc.tri.size();
+            for (u32 i = 0; i < n_sph; ++i) testSphere(sc.sph[i]);
+            for (u32 i = 0; i < (u32)sc.tri.size(); ++i) testTriangle(sc.tri[i], n_sph + i);
         }
         if (ibest < 0) {                                                     // miss, src/renderer.zig:124-125
             const R t = R(0.5) * (ud.y + R(1));
@@ -852,14 +927,23 @@ static PathResult<R> tracePath(const SceneB<R>& sc, const CamB<R>& cam, const Ra
             return res;
         }
         // --- hit record, src/geom.zig:63-65 + src/hit.zig:25-41 ---
-        const Sph<R>& q = sc.sph[sc.by_pool[ibest]];
         const V<R> pt{fm(d.x, tbest, o.x), fm(d.y, tbest, o.y), fm(d.z, tbest, o.z)};
-        const V<R> cn{fm(q.v.x, time, q.c.x), fm(q.v.y, time, q.c.y), fm(q.v.z, time, q.c.z)};
-        V<R> nrm = unit(V<R>{pt.x - cn.x, pt.y - cn.y, pt.z - cn.z});
+        V<R> nrm;
+        u32 mat_idx;
+        if ((u32)ibest < n_sph) {
+            const Sph<R>& q = sc.sph[sc.by_pool[ibest]];
+            const V<R> cn{fm(q.v.x, time, q.c.x), fm(q.v.y, time, q.c.y), fm(q.v.z, time, q.c.z)};
+            nrm = unit(V<R>{pt.x - cn.x, pt.y - cn.y, pt.z - cn.z});
+            mat_idx = q.mat;
+        } else {
+            const Tri<R>& q = sc.tri[(u32)ibest - n_sph];
+            nrm = unit(cross3(q.e1, q.e2));
+            mat_idx = q.mat;
+        }
         const bool front = dot3(nrm, d) < R(0);
         if (!front) nrm = neg(nrm);
 
-        const Mat<R>& m = sc.mats[q.mat];
+        const Mat<R>& m = sc.mats[mat_idx];
         V<R> nd, att;
         if (m.kind == RAYZ_MAT_DIFFUSE) {                                    // src/material.zig:77-101
             V<R> target;
@@ -1001,8 +1085,15 @@ static A::Scene sceneA(const RayzSceneDesc& d) {
     }
     sc.materials.assign(d.materials, d.materials + d.n_materials);
     sc.textures.assign(d.textures, d.textures + d.n_textures);
+    for (u32 i = 0; i < d.n_triangles; ++i) {
+        A::Triangle t;
+        t.v0 = A::v3(d.triangles[i].v0), t.v1 = A::v3(d.triangles[i].v1), t.v2 = A::v3(d.triangles[i].v2);
+        t.material = d.triangles[i].material;
+        sc.triangles.push_back(t);
+    }
     for (u32 i = 0; i < d.n_spheres; ++i)                                    // src/ecs.zig:43-51
         sc.hittables.push_back({sc.spheres[i].boundingBox(), i});
+    for (u32 i = 0; i < d.n_triangles; ++i) sc.hittables.push_back({sc.triangles[i].boundingBox(), d.n_spheres + i});
     return sc;
 }
 

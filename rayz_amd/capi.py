@@ -12,7 +12,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "librayz_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 OK = 0
 ERR_BAD_ARG = -1
@@ -45,10 +45,14 @@ class Sphere(C.Structure):
                 ("_pad", C.c_uint32)]
 
 
+class Triangle(C.Structure):
+    _fields_ = [("v0", D3), ("v1", D3), ("v2", D3), ("material", C.c_uint32), ("_pad", C.c_uint32)]
+
+
 class SceneDesc(C.Structure):
     _fields_ = [("spheres", C.POINTER(Sphere)), ("materials", C.POINTER(Material)),
                 ("textures", C.POINTER(Texture)), ("n_spheres", C.c_uint32), ("n_materials", C.c_uint32),
-                ("n_textures", C.c_uint32), ("_pad", C.c_uint32)]
+                ("n_textures", C.c_uint32), ("n_triangles", C.c_uint32), ("triangles", C.POINTER(Triangle))]
 
 
 class CameraDesc(C.Structure):
@@ -68,7 +72,8 @@ class RenderStats(C.Structure):
                 ("node_tests", C.c_uint64), ("kernel_ms", C.c_double)]
 
 
-assert C.sizeof(Texture) == 48 and C.sizeof(Material) == 24 and C.sizeof(Sphere) == 64
+assert C.sizeof(Texture) == 48 and C.sizeof(Material) == 24 and C.sizeof(Sphere) == 64 and C.sizeof(Triangle) == 80
+assert C.sizeof(SceneDesc) == 48
 assert C.sizeof(CameraDesc) == 152 and C.sizeof(RenderParams) == 56 and C.sizeof(RenderStats) == 40
 
 # every symbol include/rayz_hip.h declares: (name, restype, argtypes)

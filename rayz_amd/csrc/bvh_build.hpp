@@ -46,6 +46,17 @@ inline Box sphereBox(const RayzSphere& s) { // Sphere.boundingBox, src/geom.zig:
     return b;
 }
 
+// Build-defined triangle hittable: vertex bounds padded by 1e-4 per side (a flat box can never pass the
+// reference's strict `t1 > t0`, src/hit.zig:97).
+inline Box triangleBox(const RayzTriangle& t) {
+    Box b;
+    for (int k = 0; k < 3; ++k) {
+        b.lo[k] = std::fmin(std::fmin(t.v0[k], t.v1[k]), t.v2[k]) - 1e-4;
+        b.hi[k] = std::fmax(std::fmax(t.v0[k], t.v1[k]), t.v2[k]) + 1e-4;
+    }
+    return b;
+}
+
 struct FlatNode {
     Box box;
     uint32_t skip;  // index of the next node when this subtree is done or culled (== n_nodes at the end)
@@ -55,7 +66,7 @@ struct FlatNode {
 
 struct FlatBvh {
     std::vector<FlatNode> nodes;  // depth-first pre-order
-    std::vector<uint32_t> order;  // pool indices of the hittables after the in-place sorts, i.e. leaf order
+    std::vector<uint32_t> order;  // hittable indices after the in-place sorts, i.e. leaf order
     uint32_t depth = 0;
 };
 
@@ -89,11 +100,14 @@ inline void build(std::vector<Item>& h, size_t si, size_t ei, FlatBvh& out, uint
 }
 } // namespace detail
 
-inline FlatBvh build(const std::vector<RayzSphere>& spheres) {
+// Hittables are numbered spheres first, then triangles (src/ecs.zig:43-51 order, triangles appended).
+inline FlatBvh build(const std::vector<RayzSphere>& spheres, const std::vector<RayzTriangle>& triangles) {
     FlatBvh out;
-    if (spheres.empty()) return out;
-    std::vector<detail::Item> h(spheres.size());
+    if (spheres.empty() && triangles.empty()) return out;
+    std::vector<detail::Item> h(spheres.size() + triangles.size());
     for (size_t i = 0; i < spheres.size(); ++i) h[i] = {sphereBox(spheres[i]), (uint32_t)i};
+    for (size_t i = 0; i < triangles.size(); ++i)
+        h[spheres.size() + i] = {triangleBox(triangles[i]), (uint32_t)(spheres.size() + i)};
     detail::build(h, 0, h.size(), out, 1);
     out.order.resize(h.size());
     for (size_t i = 0; i < h.size(); ++i) out.order[i] = h[i].pool;

@@ -32,6 +32,7 @@ constexpr int kMaxTextureDepth = 8;
 constexpr int kStaticGroup = 4; // spheres per scan group, by velocity class.  A stream is padded to a whole
 constexpr int kMovYGroup = 4;   //   number of group PAIRS plus one spare group, so that the prefetch of the
 constexpr int kMovGGroup = 2;   //   next group never leaves the array.
+constexpr int kTriGroup = 2;
 
 template <class R> struct VecOf;
 template <> struct VecOf<float> { typedef f4 type; };
@@ -57,11 +58,16 @@ template <class R> struct DevScene {
     const r4* mat;           // [n_mat] {bits(kind | method << 8), bits(texture), param, 1/param}
     const r4* tex;           // [2 * n_tex] {bits(kind), bits(even), bits(odd), scale}, {r, g, b, 0}
     uint32_t ns_pad, ny_pad, ng_pad, n_spheres;
+    // build-defined triangles (hittable index = n_spheres + i): {v0, bits(material)}, {e1 = v1 - v0, 0}, {e2 = v2 - v0, 0};
+    // pool order, padded with degenerate records (e1 = e2 = 0: det = 0, never accepted) like the sphere streams
+    const r4* tri;           // [3 * (nt_pad + kTriGroup)]
+    uint32_t nt_pad, n_triangles;
     // BVH traversal (RAYZ_TRAVERSAL_BVH): the reference's tree in depth-first pre-order, DESIGN.md §6
-    const r4* bvh_nodes;     // [2 * n_nodes] {lo.x, lo.y, lo.z, bits(skip)}, {hi.x, hi.y, hi.z, bits(first << 2 | count)}
-    const r4* bvh_sph;       // [2 * n_spheres] leaf order: {cx, cy, cz, r²}, {vx, vy, vz, bits(pool)}
-    const d4* bvh_sph64;     // [2 * n_spheres] leaf order: {cx, cy, cz, r²}, {vx, vy, vz, 0}
-    uint32_t bvh_n_nodes, _pad0, _pad1, _pad2;
+    const r4* bvh_nodes;     // [2 * n_nodes] {lo, bits(skip)}, {hi, bits(first << 4 | type1 << 3 | type0 << 2 | count)}
+    const r4* bvh_leaf;      // [stride * slots] leaf order.  sphere: {c, r²}, {v, bits(hittable)};
+                             //                  triangle: {v0, bits(hittable)}, {e1, 0}, {e2, 0}
+    const d4* bvh_sph64;     // [2 * slots] leaf order, sphere slots only: {c, r²}, {v, 0}
+    uint32_t bvh_n_nodes, bvh_leaf_stride;
 };
 
 template <class R> struct DevCamera {
@@ -221,6 +227,44 @@ template <class R, int N> __device__ __forceinline__ R max_of(const R (&v)[N]) {
     return m;
 }
 
+template <class R> __device__ __forceinline__ V<R> cross3(V<R> a, V<R> b) {
+    return {fm(a.y, b.z, -(a.z * b.y)), fm(a.z, b.x, -(a.x * b.z)), fm(a.x, b.y, -(a.y * b.x))};
+}
+__device__ __forceinline__ float mn(float a, float b) { return __builtin_fminf(a, b); }
+__device__ __forceinline__ double mn(double a, double b) { return __builtin_fmin(a, b); }
+
+// ---- build-defined triangle (Möller–Trumbore in R) ----------------------------------
+// Filter value: ≥ 0 iff the barycentrics pass, written without a division or a sign branch:
+// su = (s·p)·det, sv = (d·q)·det, w = det² − (su + sv); candidate iff min(su, sv, w) ≥ 0.
+template <class R> __device__ __forceinline__ R tri_filter(V<R> v0, V<R> e1, V<R> e2, V<R> o, V<R> d) {
+    const V<R> pv = cross3(d, e2);
+    const R det = dot3(e1, pv);
+    const V<R> sv{o.x - v0.x, o.y - v0.y, o.z - v0.z};
+    const R su = dot3(sv, pv) * det;
+    const V<R> qv = cross3(sv, e1);
+    const R svv = dot3(d, qv) * det;
+    const R w = fm(det, det, -(su + svv));
+    return mn(mn(su, svv), w);
+}
+// Candidate: t = (e2·q) / det, then the same acceptance rule as spheres (nearest, ties to the larger index).
+template <class R>
+__device__ __forceinline__ void tri_accept(R filt, V<R> v0, V<R> e1, V<R> e2, V<R> o, V<R> d, R tmin, int prim, R& tbest,
+                                           int& ibest) {
+    if (filt >= R(0)) {
+        const V<R> pv = cross3(d, e2);
+        const R det = dot3(e1, pv);
+        if (det != R(0)) {
+            const V<R> sv{o.x - v0.x, o.y - v0.y, o.z - v0.z};
+            const V<R> qv = cross3(sv, e1);
+            const R t = dot3(e2, qv) / det;
+            if (t >= tmin && (t < tbest || (t == tbest && prim > ibest))) {
+                tbest = t;
+                ibest = prim;
+            }
+        }
+    }
+}
+
 // One scan group of a velocity class, held in SGPRs: load() issues the scalar loads, test() runs the
 // reject test of its spheres against 64 rays and sends candidates to the narrow phase.
 template <class R, int CLS> struct ScanGroup;
@@ -326,6 +370,47 @@ __device__ __forceinline__ void scan_class(const DevScene<R>& sc, int n, V<R> o,
     }
 }
 
+// Triangle stream of the flat list: same ping-pong scalar prefetch, groups of kTriGroup.
+template <class R> struct TriGroup {
+    typedef typename VecOf<R>::type r4;
+    r4 a[kTriGroup], b[kTriGroup], c[kTriGroup];
+    __device__ __forceinline__ void load(const DevScene<R>& sc, int i) {
+        const RAYZ_CONSTANT r4* p = (const RAYZ_CONSTANT r4*)sc.tri + 3 * i;
+#pragma unroll
+        for (int k = 0; k < kTriGroup; ++k) a[k] = p[3 * k], b[k] = p[3 * k + 1], c[k] = p[3 * k + 2];
+    }
+    __device__ __forceinline__ void touch() const { asm volatile("" ::"s"(a[0].x)); }
+    __device__ __forceinline__ void test(const DevScene<R>& sc, int i, V<R> o, V<R> d, R tmin, R& tbest, int& ibest) const {
+        R f[kTriGroup];
+#pragma unroll
+        for (int k = 0; k < kTriGroup; ++k)
+            f[k] = tri_filter<R>(V<R>{a[k].x, a[k].y, a[k].z}, V<R>{b[k].x, b[k].y, b[k].z}, V<R>{c[k].x, c[k].y, c[k].z}, o, d);
+        if (max_of(f) >= R(0)) {
+#pragma unroll
+            for (int k = 0; k < kTriGroup; ++k)
+                tri_accept<R>(f[k], V<R>{a[k].x, a[k].y, a[k].z}, V<R>{b[k].x, b[k].y, b[k].z},
+                              V<R>{c[k].x, c[k].y, c[k].z}, o, d, tmin, (int)sc.n_spheres + i + k, tbest, ibest);
+        }
+    }
+};
+template <class R>
+__device__ __forceinline__ void scan_triangles(const DevScene<R>& sc, V<R> o, V<R> d, R tmin, R& tbest, int& ibest) {
+    const int n = (int)sc.nt_pad;
+    if (n == 0) return;
+    TriGroup<R> a, b;
+    a.load(sc, 0);
+    for (int i = 0; i < n; i += 2 * kTriGroup) {
+        a.touch();
+        b.load(sc, i + kTriGroup);
+        __builtin_amdgcn_sched_barrier(0);
+        a.test(sc, i, o, d, tmin, tbest, ibest);
+        b.touch();
+        a.load(sc, i + 2 * kTriGroup);
+        __builtin_amdgcn_sched_barrier(0);
+        b.test(sc, i + kTriGroup, o, d, tmin, tbest, ibest);
+    }
+}
+
 // ---- the flat-list scan: nearest hit of ray (o, d, time) over every sphere ---------------------
 // Wave-uniform in the sphere index: records arrive by scalar loads and feed the VALU as SGPR operands.
 template <class R>
@@ -338,6 +423,7 @@ __device__ __forceinline__ void scan_spheres(const DevScene<R>& sc, V<R> o, V<R>
     scan_class<R, 0>(sc, (int)sc.ns_pad, o, d, ud, time, inv_a2, tmin, tbest, ibest);
     scan_class<R, 1>(sc, (int)sc.ny_pad, o, d, ud, time, inv_a2, tmin, tbest, ibest);
     scan_class<R, 2>(sc, (int)sc.ng_pad, o, d, ud, time, inv_a2, tmin, tbest, ibest);
+    scan_triangles<R>(sc, o, d, tmin, tbest, ibest);
 }
 
 // ---- shading of one segment: returns false when the path ends ------------------------------------
@@ -356,16 +442,25 @@ __device__ __forceinline__ bool shade(const DevScene<R>& sc, Pcg32& g, V<R>& o, 
         acc.z = acc.z + thr.z * col.z;
         return false;
     }
-    // hit record: src/geom.zig:63-65, src/hit.zig:25-41
-    const r4 q = sc.sph_pool[2 * ibest], w4 = sc.sph_pool[2 * ibest + 1];
-    const V<R> c{q.x, q.y, q.z}, v{w4.x, w4.y, w4.z};
+    // hit record: src/geom.zig:63-65, src/hit.zig:25-41 (spheres); geometric normal for triangles
     const V<R> pt{fm(d.x, tbest, o.x), fm(d.y, tbest, o.y), fm(d.z, tbest, o.z)};
-    const V<R> cn{fm(v.x, time, c.x), fm(v.y, time, c.y), fm(v.z, time, c.z)};
-    V<R> nrm = unit(V<R>{pt.x - cn.x, pt.y - cn.y, pt.z - cn.z});
+    V<R> nrm;
+    uint32_t mat_idx;
+    if ((uint32_t)ibest < sc.n_spheres) {
+        const r4 q = sc.sph_pool[2 * ibest], w4 = sc.sph_pool[2 * ibest + 1];
+        const V<R> cn{fm(w4.x, time, q.x), fm(w4.y, time, q.y), fm(w4.z, time, q.z)};
+        nrm = unit(V<R>{pt.x - cn.x, pt.y - cn.y, pt.z - cn.z});
+        mat_idx = bits(w4.w);
+    } else {
+        const uint32_t ti = (uint32_t)ibest - sc.n_spheres;
+        const r4 a = sc.tri[3 * ti], b = sc.tri[3 * ti + 1], c = sc.tri[3 * ti + 2];
+        nrm = unit(cross3(V<R>{b.x, b.y, b.z}, V<R>{c.x, c.y, c.z}));
+        mat_idx = bits(a.w);
+    }
     const bool front = dot3(nrm, d) < R(0);
     if (!front) nrm = neg(nrm);
 
-    const r4 m = sc.mat[bits(w4.w)];
+    const r4 m = sc.mat[mat_idx];
     const uint32_t kind = bits(m.x) & 0xffu, method = (bits(m.x) >> 8) & 0xffu, texture = bits(m.y);
     const R param = m.z, inv_param = m.w;
     V<R> nd, att;
@@ -551,9 +646,6 @@ template <class R> struct Slack;
 template <> struct Slack<float> { static constexpr float v = 1.0f + 4.0f * 1.1920929e-07f; };
 template <> struct Slack<double> { static constexpr double v = 1.0 + 4.0 * 2.220446049250313e-16; };
 
-__device__ __forceinline__ float mn(float a, float b) { return __builtin_fminf(a, b); }
-__device__ __forceinline__ double mn(double a, double b) { return __builtin_fmin(a, b); }
-
 // One node step of a lane: slab test (AABB.hit, src/hit.zig:70-98, with 1/d hoisted and a 4-ulp slack so that
 // rounding never culls a box the f64 narrow phase would hit), then either descend, test the leaf's ≤ 2 spheres,
 // or follow the skip link.
@@ -571,15 +663,23 @@ __device__ __forceinline__ void bvh_step(const DevScene<R>& sc, BvhQuery<R>& q, 
     uint32_t next = bits(a.w);
     if (t1 * Slack<R>::v >= t0) {
         const uint32_t leaf = bits(b.w);
-        const uint32_t cnt = leaf & 3u, first = leaf >> 2;
+        const uint32_t cnt = leaf & 3u, first = leaf >> 4;
         if (cnt == 0u) next = q.idx + 1u;
         for (uint32_t k = 0; k < cnt; ++k) {
-            const r4 c = sc.bvh_sph[2 * (first + k)], v = sc.bvh_sph[2 * (first + k) + 1];
+            const uint32_t slot = first + k;
+            const r4* rec = sc.bvh_leaf + (size_t)sc.bvh_leaf_stride * slot;
+            const r4 c = rec[0], v = rec[1];
             sphere_tests++;
+            if ((leaf >> (2u + k)) & 1u) { // triangle
+                const r4 e2 = rec[2];
+                const V<R> v0{c.x, c.y, c.z}, e1{v.x, v.y, v.z}, ee2{e2.x, e2.y, e2.z};
+                tri_accept<R>(tri_filter<R>(v0, e1, ee2, o, d), v0, e1, ee2, o, d, tmin, (int)bits(c.w), q.tbest, q.ibest);
+                continue;
+            }
             const R disc = reject_disc<R>(fm(v.x, time, c.x - o.x), fm(v.y, time, c.y - o.y), fm(v.z, time, c.z - o.z),
                                           c.w, ud);
             if (disc >= R(0)) {
-                const d4 c2 = sc.bvh_sph64[2 * (first + k)], v2 = sc.bvh_sph64[2 * (first + k) + 1];
+                const d4 c2 = sc.bvh_sph64[2 * slot], v2 = sc.bvh_sph64[2 * slot + 1];
                 const double dx = d.x, dy = d.y, dz = d.z, tm = time;
                 const double qx = fm(v2.x, tm, c2.x - (double)o.x), qy = fm(v2.y, tm, c2.y - (double)o.y),
                              qz = fm(v2.z, tm, c2.z - (double)o.z);

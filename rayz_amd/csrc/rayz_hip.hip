@@ -67,13 +67,16 @@ template <class R> struct SceneBuffers {
     r4* sph_pool = nullptr;
     r4* mat = nullptr;
     r4* tex = nullptr;
+    r4* tri = nullptr;
     r4* bvh_nodes = nullptr; // BVH traversal only
-    r4* bvh_sph = nullptr;
+    r4* bvh_leaf = nullptr;
+    uint32_t nt_pad = 0, bvh_leaf_stride = 2;
     bool ready = false, bvh_ready = false;
     void release() {
+        (void)hipFree(tri);
         (void)hipFree(bvh_nodes);
-        (void)hipFree(bvh_sph);
-        bvh_nodes = bvh_sph = nullptr;
+        (void)hipFree(bvh_leaf);
+        tri = bvh_nodes = bvh_leaf = nullptr;
         bvh_ready = false;
         (void)hipFree(stat);
         (void)hipFree(movy);
@@ -119,6 +122,7 @@ struct RayzScene {
     std::vector<RayzSphere> spheres;
     std::vector<RayzMaterial> materials;
     std::vector<RayzTexture> textures;
+    std::vector<RayzTriangle> triangles;
     SceneBuffers<float> f32;
     SceneBuffers<double> f64;
     NarrowBuffers narrow;
@@ -221,6 +225,16 @@ template <class R> int upload(RayzScene* s, SceneBuffers<R>& b) {
         movg[2 * k] = rec(s->cls[2][k]);
         movg[2 * k + 1] = r4{(R)q.velocity[0], (R)q.velocity[1], (R)q.velocity[2], R(0)};
     }
+    // triangles: {v0, bits(material)}, {e1, 0}, {e2, 0}; edges subtracted in f64, then narrowed
+    b.nt_pad = scan_len(s->triangles.size(), kTriGroup);
+    std::vector<r4> tri(3 * (size_t)(b.nt_pad + kTriGroup), r4{R(0), R(0), R(0), R(0)});
+    for (size_t k = 0; k < s->triangles.size(); ++k) {
+        const RayzTriangle& q = s->triangles[k];
+        tri[3 * k] = r4{(R)q.v0[0], (R)q.v0[1], (R)q.v0[2], Bits<R>::from(q.material)};
+        tri[3 * k + 1] = r4{(R)(q.v1[0] - q.v0[0]), (R)(q.v1[1] - q.v0[1]), (R)(q.v1[2] - q.v0[2]), R(0)};
+        tri[3 * k + 2] = r4{(R)(q.v2[0] - q.v0[0]), (R)(q.v2[1] - q.v0[1]), (R)(q.v2[2] - q.v0[2]), R(0)};
+    }
+    HIP_TRY(put(&b.tri, tri));
     std::vector<r4> sph_pool, mat, tex;
     for (uint32_t i = 0; i < s->spheres.size(); ++i) {
         const RayzSphere& q = s->spheres[i];
@@ -248,7 +262,7 @@ template <class R> int upload(RayzScene* s, SceneBuffers<R>& b) {
 
 void ensure_bvh(RayzScene* s) {
     if (!s->bvh_built) {
-        s->bvh = rayz_bvh::build(s->spheres); // replaces initHittables + bvh.build, src/renderer.zig:76-78
+        s->bvh = rayz_bvh::build(s->spheres, s->triangles); // replaces initHittables + bvh.build, src/renderer.zig:76-78
         s->bvh_built = true;
     }
 }
@@ -257,40 +271,62 @@ template <class R> int upload_bvh(RayzScene* s, SceneBuffers<R>& b) {
     typedef typename VecOf<R>::type r4;
     ensure_bvh(s);
     const rayz_bvh::FlatBvh& t = s->bvh;
+    const uint32_t ns = (uint32_t)s->spheres.size();
     if (!s->narrow.bvh_ready) {
         std::vector<d4> sph64;
-        for (uint32_t pool : t.order) {
-            const RayzSphere& q = s->spheres[pool];
-            sph64.push_back(d4{q.center[0], q.center[1], q.center[2], q.radius * q.radius});
-            sph64.push_back(d4{q.velocity[0], q.velocity[1], q.velocity[2], 0.0});
+        for (uint32_t prim : t.order) {
+            if (prim < ns) {
+                const RayzSphere& q = s->spheres[prim];
+                sph64.push_back(d4{q.center[0], q.center[1], q.center[2], q.radius * q.radius});
+                sph64.push_back(d4{q.velocity[0], q.velocity[1], q.velocity[2], 0.0});
+            } else { // triangle slot: unused by the narrow phase
+                sph64.push_back(d4{0, 0, 0, 0});
+                sph64.push_back(d4{0, 0, 0, 0});
+            }
         }
         HIP_TRY(put(&s->narrow.bvh_sph64, sph64));
         s->narrow.bvh_ready = true;
     }
     if (b.bvh_ready) return RAYZ_OK;
-    std::vector<r4> nodes, sph;
+    b.bvh_leaf_stride = s->triangles.empty() ? 2u : 3u;
+    std::vector<r4> nodes, leaf;
     for (const rayz_bvh::FlatNode& n : t.nodes) { // boxes narrowed outward: never smaller than the f64 box
+        uint32_t info = (n.first << 4) | n.count;
+        for (uint32_t k = 0; k < n.count; ++k)
+            if (t.order[n.first + k] >= ns) info |= 1u << (2 + k);
         nodes.push_back(r4{rayz_bvh::roundDown<R>(n.box.lo[0]), rayz_bvh::roundDown<R>(n.box.lo[1]),
                            rayz_bvh::roundDown<R>(n.box.lo[2]), Bits<R>::from(n.skip)});
         nodes.push_back(r4{rayz_bvh::roundUp<R>(n.box.hi[0]), rayz_bvh::roundUp<R>(n.box.hi[1]),
-                           rayz_bvh::roundUp<R>(n.box.hi[2]), Bits<R>::from((n.first << 2) | n.count)});
+                           rayz_bvh::roundUp<R>(n.box.hi[2]), Bits<R>::from(info)});
     }
-    for (uint32_t pool : t.order) {
-        const RayzSphere& q = s->spheres[pool];
-        const R r = (R)q.radius;
-        sph.push_back(r4{(R)q.center[0], (R)q.center[1], (R)q.center[2], r * r});
-        sph.push_back(r4{(R)q.velocity[0], (R)q.velocity[1], (R)q.velocity[2], Bits<R>::from(pool)});
+    for (uint32_t prim : t.order) {
+        if (prim < ns) {
+            const RayzSphere& q = s->spheres[prim];
+            const R r = (R)q.radius;
+            leaf.push_back(r4{(R)q.center[0], (R)q.center[1], (R)q.center[2], r * r});
+            leaf.push_back(r4{(R)q.velocity[0], (R)q.velocity[1], (R)q.velocity[2], Bits<R>::from(prim)});
+            if (b.bvh_leaf_stride == 3) leaf.push_back(r4{R(0), R(0), R(0), R(0)});
+        } else {
+            const RayzTriangle& q = s->triangles[prim - ns];
+            leaf.push_back(r4{(R)q.v0[0], (R)q.v0[1], (R)q.v0[2], Bits<R>::from(prim)});
+            leaf.push_back(r4{(R)(q.v1[0] - q.v0[0]), (R)(q.v1[1] - q.v0[1]), (R)(q.v1[2] - q.v0[2]), R(0)});
+            leaf.push_back(r4{(R)(q.v2[0] - q.v0[0]), (R)(q.v2[1] - q.v0[1]), (R)(q.v2[2] - q.v0[2]), R(0)});
+        }
     }
     HIP_TRY(put(&b.bvh_nodes, nodes));
-    HIP_TRY(put(&b.bvh_sph, sph));
+    HIP_TRY(put(&b.bvh_leaf, leaf));
     b.bvh_ready = true;
     return RAYZ_OK;
 }
 
 int validate_scene(const RayzSceneDesc* d) {
     if (!d) return fail(RAYZ_ERR_BAD_ARG, "scene is null");
-    if ((d->n_spheres && !d->spheres) || (d->n_materials && !d->materials) || (d->n_textures && !d->textures))
+    if ((d->n_spheres && !d->spheres) || (d->n_materials && !d->materials) || (d->n_textures && !d->textures) ||
+        (d->n_triangles && !d->triangles))
         return fail(RAYZ_ERR_BAD_ARG, "scene list pointer is null");
+    for (uint32_t i = 0; i < d->n_triangles; ++i)
+        if (d->triangles[i].material >= d->n_materials)
+            return fail(RAYZ_ERR_BAD_ARG, "triangle %u: material handle %u out of range", i, d->triangles[i].material);
     for (uint32_t i = 0; i < d->n_textures; ++i) {
         const RayzTexture& t = d->textures[i];
         if (t.kind > RAYZ_TEX_SOLID) return fail(RAYZ_ERR_BAD_ARG, "texture %u: bad kind %u", i, t.kind);
@@ -341,7 +377,8 @@ int render_impl(RayzScene* s, SceneBuffers<R>& b, const RayzCameraDesc* cam, con
     typedef typename VecOf<R>::type r4;
     if (g_device < 0) return fail(RAYZ_ERR_NO_DEVICE, "rayz_hip_init has not succeeded");
     const bool use_bvh = p->traversal == RAYZ_TRAVERSAL_BVH;
-    if (use_bvh && s->spheres.size() >= (1u << 30)) return fail(RAYZ_ERR_BAD_ARG, "too many spheres for the BVH layout");
+    if (s->spheres.size() + s->triangles.size() >= (1u << 27))
+        return fail(RAYZ_ERR_BAD_ARG, "too many hittables for the device layout");
     int rc = upload<R>(s, b);
     if (rc != RAYZ_OK) return rc;
     if (use_bvh) {
@@ -401,10 +438,14 @@ int render_impl(RayzScene* s, SceneBuffers<R>& b, const RayzCameraDesc* cam, con
     A.sc.ny_pad = s->narrow.ny_pad;
     A.sc.ng_pad = s->narrow.ng_pad;
     A.sc.n_spheres = (uint32_t)s->spheres.size();
+    A.sc.tri = b.tri;
+    A.sc.nt_pad = b.nt_pad;
+    A.sc.n_triangles = (uint32_t)s->triangles.size();
     A.sc.bvh_nodes = b.bvh_nodes;
-    A.sc.bvh_sph = b.bvh_sph;
+    A.sc.bvh_leaf = b.bvh_leaf;
     A.sc.bvh_sph64 = s->narrow.bvh_sph64;
     A.sc.bvh_n_nodes = use_bvh ? (uint32_t)s->bvh.nodes.size() : 0u;
+    A.sc.bvh_leaf_stride = b.bvh_leaf_stride;
     fill_camera<R>(cam, A.cam);
     A.partial = (r4*)s->partial;
     A.counters = s->counters;
@@ -545,6 +586,7 @@ int rayz_hip_scene_create(const RayzSceneDesc* scene, RayzScene** out) {
         s->spheres.assign(scene->spheres, scene->spheres + scene->n_spheres);
         s->materials.assign(scene->materials, scene->materials + scene->n_materials);
         s->textures.assign(scene->textures, scene->textures + scene->n_textures);
+        s->triangles.assign(scene->triangles, scene->triangles + scene->n_triangles);
     } catch (...) {
         delete s;
         return fail(RAYZ_ERR_OOM, "host allocation failed");
@@ -591,7 +633,7 @@ int rayz_hip_scene_sync(RayzScene* s, RayzRenderStats* stats) {
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
         s->last.segments = c[1];
-        s->last.sphere_tests = s->last_bvh ? c[3] : c[1] * (unsigned long long)s->spheres.size();
+        s->last.sphere_tests = s->last_bvh ? c[3] : c[1] * (unsigned long long)(s->spheres.size() + s->triangles.size());
         s->last.node_tests = s->last_bvh ? c[2] : 0;
         s->last.kernel_ms = ms;
     }

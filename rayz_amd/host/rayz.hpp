@@ -192,12 +192,24 @@ struct Sphere {
     }
 };
 
-// ---- src/ecs.zig:22-69 ----------------------------------------------------------------------------
+// ---- build-defined: a triangle hittable (the reference's geom.zig has only Sphere) --------------------
+struct Triangle {
+    V3 v0, v1, v2;
+    MaterialHandle material;
+};
+
+// ---- src/ecs.zig:22-69 (+ the triangle list) ----------------------------------------------------------
 struct MemPool {
     std::vector<Sphere> spheres;
     std::vector<Material> materials;
     std::vector<Texture> textures;
+    std::vector<Triangle> triangles;
     void add(const Sphere& s) { spheres.push_back(s); }
+    void add(const Triangle& t) { triangles.push_back(t); }
+    size_t addAndReturnHandle(const Triangle& t) {
+        triangles.push_back(t);
+        return triangles.size() - 1;
+    }
     TextureHandle addAndReturnHandle(const Texture& t) {
         textures.push_back(t);
         return {textures.size() - 1};
@@ -346,11 +358,13 @@ struct Tracer {
         std::vector<RayzSphere> spheres;
         std::vector<RayzMaterial> materials;
         std::vector<RayzTexture> textures;
+        std::vector<RayzTriangle> triangles;
         RayzSceneDesc desc() const {
             RayzSceneDesc d{};
             d.spheres = spheres.data(), d.materials = materials.data(), d.textures = textures.data();
             d.n_spheres = (uint32_t)spheres.size(), d.n_materials = (uint32_t)materials.size();
             d.n_textures = (uint32_t)textures.size();
+            d.triangles = triangles.data(), d.n_triangles = (uint32_t)triangles.size();
             return d;
         }
     };
@@ -364,6 +378,14 @@ struct Tracer {
             q.radius = s.radius;
             q.material = (uint32_t)s.material.idx;
             f.spheres.push_back(q);
+        }
+        for (const Triangle& t : pool.triangles) {
+            RayzTriangle q{};
+            q.v0[0] = t.v0.x, q.v0[1] = t.v0.y, q.v0[2] = t.v0.z;
+            q.v1[0] = t.v1.x, q.v1[1] = t.v1.y, q.v1[2] = t.v1.z;
+            q.v2[0] = t.v2.x, q.v2[1] = t.v2.y, q.v2[2] = t.v2.z;
+            q.material = (uint32_t)t.material.idx;
+            f.triangles.push_back(q);
         }
         for (const Material& m : pool.materials) {
             RayzMaterial q{};
@@ -490,6 +512,47 @@ inline Tracer threeSpheres(size_t img_w, const uint64_t* seed = nullptr) {
     pool.add(Sphere::stationary(V3{0, -100.5, -1}, 100, lambert(V3{0.8, 0.8, 0.0})));
     pool.add(Sphere::stationary(V3{0, 0, -1.2}, 0.5, lambert(V3{0.1, 0.2, 0.5})));
     pool.add(Sphere::stationary(V3{1, 0, -1}, 0.5, lambert(V3{0.8, 0.6, 0.2})));
+    return tracer;
+}
+
+// BASELINE config 5 (build-defined; no reference counterpart): an n x n-quad height field (2·n² triangles;
+// n = 224 gives 100,352) with smooth bumps, Lambertian with a checker, three spheres resting above it.
+// Heights come from an integer hash + smoothstep, so the mesh is identical on every host (no libm).
+inline Tracer triangleMesh(size_t img_w, unsigned n = 224, const uint64_t* seed = nullptr) {
+    Tracer tracer = Tracer::init(img_w, 35.0, 9.0, 0.0, V3{6.5, 4.0, 6.5}, V3{0, 0.3, 0}, V3::y_hat(), seed);
+    MemPool& pool = tracer.pool;
+    const TextureHandle a = pool.addAndReturnHandle(Texture::Solid(V3{0.75, 0.7, 0.6}));
+    const TextureHandle b = pool.addAndReturnHandle(Texture::Solid(V3{0.35, 0.45, 0.3}));
+    const MaterialHandle ground = pool.addAndReturnHandle(Material::Diffuse(pool.addAndReturnHandle(Texture::Checker(0.8, a, b))));
+    auto hash = [](uint32_t x, uint32_t y) {
+        uint32_t h = x * 0x9E3779B1u ^ (y + 0x7F4A7C15u) * 0x85EBCA6Bu;
+        h ^= h >> 15, h *= 0x2C1B3C6Du, h ^= h >> 12, h *= 0x297A2D39u, h ^= h >> 15;
+        return (double)(h >> 8) * (1.0 / 16777216.0);
+    };
+    const double extent = 5.0, cell = 2 * extent / n;
+    const unsigned coarse = 14; // bump lattice
+    auto height = [&](unsigned i, unsigned j) {
+        const double fx = (double)i * coarse / n, fy = (double)j * coarse / n;
+        const unsigned x0 = (unsigned)fx, y0 = (unsigned)fy;
+        double tx = fx - x0, ty = fy - y0;
+        tx = tx * tx * (3 - 2 * tx), ty = ty * ty * (3 - 2 * ty);
+        const double h00 = hash(x0, y0), h10 = hash(x0 + 1, y0), h01 = hash(x0, y0 + 1), h11 = hash(x0 + 1, y0 + 1);
+        return 0.45 * ((h00 * (1 - tx) + h10 * tx) * (1 - ty) + (h01 * (1 - tx) + h11 * tx) * ty);
+    };
+    auto vert = [&](unsigned i, unsigned j) { return V3{-extent + i * cell, height(i, j), -extent + j * cell}; };
+    for (unsigned j = 0; j < n; ++j)
+        for (unsigned i = 0; i < n; ++i) {
+            const V3 p00 = vert(i, j), p10 = vert(i + 1, j), p01 = vert(i, j + 1), p11 = vert(i + 1, j + 1);
+            pool.add(Triangle{p00, p01, p11, ground});
+            pool.add(Triangle{p00, p11, p10, ground});
+        }
+    pool.add(Sphere::stationary(V3{0, 1.1, 0}, 0.7, pool.addAndReturnHandle(Material::Dielectric(1.5))));
+    pool.add(Sphere::stationary(
+        V3{-1.9, 0.95, 0.6}, 0.55,
+        pool.addAndReturnHandle(Material::Metallic(pool.addAndReturnHandle(Texture::Solid(V3{0.8, 0.7, 0.5})), 0.05))));
+    pool.add(Sphere::stationary(
+        V3{1.7, 0.9, -0.8}, 0.5,
+        pool.addAndReturnHandle(Material::Diffuse(pool.addAndReturnHandle(Texture::Solid(V3{0.7, 0.15, 0.1}))))));
     return tracer;
 }
 

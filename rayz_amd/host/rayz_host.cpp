@@ -75,6 +75,12 @@ int64_t rayz_tracer_add_sphere(RayzTracer* t, const double* center, const double
     return (int64_t)t->t.pool.addAndReturnHandle(s);
 }
 
+int64_t rayz_tracer_add_triangle(RayzTracer* t, const double* v0, const double* v1, const double* v2, uint32_t material) {
+    if (!t || !v0 || !v1 || !v2) return RAYZ_ERR_BAD_ARG;
+    t->flat_valid = false;
+    return (int64_t)t->t.pool.addAndReturnHandle(Triangle{v3(v0), v3(v1), v3(v2), {material}});
+}
+
 int rayz_tracer_set_u64(RayzTracer* t, int field, uint64_t v) {
     if (!t) return RAYZ_ERR_BAD_ARG;
     switch (field) {
@@ -107,7 +113,7 @@ int rayz_tracer_info(const RayzTracer* t, RayzTracerInfo* o) {
     o->width = (uint32_t)t->t.img.w, o->height = (uint32_t)t->t.img.h;
     o->samples_per_px = (uint32_t)t->t.samples_per_px, o->max_bounces = (uint32_t)t->t.max_bounces;
     o->n_spheres = (uint32_t)t->t.pool.spheres.size(), o->n_materials = (uint32_t)t->t.pool.materials.size();
-    o->n_textures = (uint32_t)t->t.pool.textures.size(), o->_pad = 0;
+    o->n_textures = (uint32_t)t->t.pool.textures.size(), o->n_triangles = (uint32_t)t->t.pool.triangles.size();
     return RAYZ_OK;
 }
 int rayz_tracer_camera(const RayzTracer* t, RayzCameraDesc* out) {
@@ -204,6 +210,15 @@ int rayz_scene_random_bouncing(uint32_t img_w, int lo, int hi, int has_seed, uin
     *out = nullptr;
     try {
         return wrap(randomBouncing(img_w, lo, hi, has_seed ? &seed : nullptr), out);
+    } catch (...) {
+        return RAYZ_ERR_OOM;
+    }
+}
+int rayz_scene_triangle_mesh(uint32_t img_w, uint32_t n, int has_seed, uint64_t seed, RayzTracer** out) {
+    if (!out || img_w == 0 || n == 0 || n > 4096) return RAYZ_ERR_BAD_ARG;
+    *out = nullptr;
+    try {
+        return wrap(triangleMesh(img_w, n, has_seed ? &seed : nullptr), out);
     } catch (...) {
         return RAYZ_ERR_OOM;
     }

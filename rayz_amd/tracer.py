@@ -20,7 +20,7 @@ FIELD_CHUNK_SPP, FIELD_RENDER_SEED, FIELD_TMIN = 4, 5, 6
 class TracerInfo(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("samples_per_px", C.c_uint32),
                 ("max_bounces", C.c_uint32), ("n_spheres", C.c_uint32), ("n_materials", C.c_uint32),
-                ("n_textures", C.c_uint32), ("_pad", C.c_uint32)]
+                ("n_textures", C.c_uint32), ("n_triangles", C.c_uint32)]
 
 
 _P = C.POINTER
@@ -35,6 +35,7 @@ HOST_PROTOTYPES = [
     ("rayz_tracer_add_material_metallic", C.c_int64, [C.c_void_p, C.c_uint32, C.c_double]),
     ("rayz_tracer_add_material_dielectric", C.c_int64, [C.c_void_p, C.c_double]),
     ("rayz_tracer_add_sphere", C.c_int64, [C.c_void_p, _D, _D, C.c_double, C.c_uint32]),
+    ("rayz_tracer_add_triangle", C.c_int64, [C.c_void_p, _D, _D, _D, C.c_uint32]),
     ("rayz_tracer_set_u64", C.c_int, [C.c_void_p, C.c_int, C.c_uint64]),
     ("rayz_tracer_set_f64", C.c_int, [C.c_void_p, C.c_int, C.c_double]),
     ("rayz_tracer_info", C.c_int, [C.c_void_p, _P(TracerInfo)]),
@@ -53,6 +54,7 @@ HOST_PROTOTYPES = [
     ("rayz_image_to_u8", None, [_D, C.c_size_t, _P(C.c_uint8)]),
     ("rayz_scene_random_bouncing", C.c_int, [C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_uint64, _P(C.c_void_p)]),
     ("rayz_scene_three_spheres", C.c_int, [C.c_uint32, C.c_int, C.c_uint64, _P(C.c_void_p)]),
+    ("rayz_scene_triangle_mesh", C.c_int, [C.c_uint32, C.c_uint32, C.c_int, C.c_uint64, _P(C.c_void_p)]),
 ]
 
 _bound = False
@@ -103,6 +105,11 @@ class MemPool:
     def add_sphere(self, center, radius: float, material: int, velocity=(0.0, 0.0, 0.0)) -> int:
         return self._h(_lib().rayz_tracer_add_sphere(self._t._h, _d3(center), _d3(velocity), radius, material),
                        "sphere")
+
+
+    def add_triangle(self, v0, v1, v2, material: int) -> int:
+        """Build-defined triangle hittable (the reference has spheres only)."""
+        return self._h(_lib().rayz_tracer_add_triangle(self._t._h, _d3(v0), _d3(v1), _d3(v2), material), "triangle")
 
 
 class Image:
@@ -236,6 +243,15 @@ def randomBouncing(img_w: int, grid_lo: int = -11, grid_hi: int = 11, seed: int 
     rc = _lib().rayz_scene_random_bouncing(img_w, grid_lo, grid_hi, 0 if seed is None else 1, seed or 0, C.byref(h))
     if rc != capi.OK:
         raise capi.RayzHipError(f"randomBouncing failed (status {rc})")
+    return Tracer(h.value)
+
+
+def triangleMesh(img_w: int, n: int = 224, seed: int | None = None) -> Tracer:
+    """BASELINE config 5 (build-defined): n x n-quad height field (2 n^2 triangles) + three spheres."""
+    h = C.c_void_p()
+    rc = _lib().rayz_scene_triangle_mesh(img_w, n, 0 if seed is None else 1, seed or 0, C.byref(h))
+    if rc != capi.OK:
+        raise capi.RayzHipError(f"triangleMesh failed (status {rc})")
     return Tracer(h.value)
 
 

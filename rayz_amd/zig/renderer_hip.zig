@@ -36,6 +36,13 @@ pub const RayzSphere = extern struct {
     material: u32,
     _pad: u32 = 0,
 };
+pub const RayzTriangle = extern struct { // build-defined hittable; the reference has none (leave the list empty)
+    v0: [3]f64,
+    v1: [3]f64,
+    v2: [3]f64,
+    material: u32,
+    _pad: u32 = 0,
+};
 pub const RayzSceneDesc = extern struct {
     spheres: ?[*]const RayzSphere,
     materials: ?[*]const RayzMaterial,
@@ -43,7 +50,8 @@ pub const RayzSceneDesc = extern struct {
     n_spheres: u32,
     n_materials: u32,
     n_textures: u32,
-    _pad: u32 = 0,
+    n_triangles: u32 = 0,
+    triangles: ?[*]const RayzTriangle = null,
 };
 pub const RayzCameraDesc = extern struct {
     look_from: [3]f64,

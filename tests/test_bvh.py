@@ -24,7 +24,7 @@ def product_tree(t):
     N = n.value
     boxes = np.zeros((N, 6))
     skip, first, count = (np.zeros(N, np.uint32) for _ in range(3))
-    order = np.zeros(sd.n_spheres, np.uint32)
+    order = np.zeros(sd.n_spheres + sd.n_triangles, np.uint32)
     assert lib.rayz_hip_scene_bvh(h, C.byref(n), None, boxes.ctypes.data_as(_P(C.c_double)),
                                   skip.ctypes.data_as(_P(C.c_uint32)), first.ctypes.data_as(_P(C.c_uint32)),
                                   count.ctypes.data_as(_P(C.c_uint32)), order.ctypes.data_as(_P(C.c_uint32))) == capi.OK
@@ -38,7 +38,7 @@ def oracle_tree(oracle, t):
     N = lib.rayz_oracle_bvh_flat(C.byref(sd), None, None, None, None, None)
     boxes = np.zeros((N, 6))
     skip, first, count = (np.zeros(N, np.uint32) for _ in range(3))
-    order = np.zeros(sd.n_spheres, np.uint32)
+    order = np.zeros(sd.n_spheres + sd.n_triangles, np.uint32)
     lib.rayz_oracle_bvh_flat(C.byref(sd), boxes.ctypes.data_as(_P(C.c_double)), skip.ctypes.data_as(_P(C.c_uint32)),
                              first.ctypes.data_as(_P(C.c_uint32)), count.ctypes.data_as(_P(C.c_uint32)),
                              order.ctypes.data_as(_P(C.c_uint32)))
@@ -50,6 +50,7 @@ def _scenes():
     yield "grid3", tracer.randomBouncing(64, -3, 3, seed=5)
     yield "10k", tracer.randomBouncing(64, -50, 50, seed=42)
     yield "three", tracer.threeSpheres(64, seed=1)
+    yield "mesh", tracer.triangleMesh(64, 12, seed=1)
     t = tracer.Tracer.init(64, 20, 1, 0, (0, 0, 3), (0, 0, 0), (0, 1, 0), seed=1)
     tx = t.pool.add_solid_texture((0.5, 0.5, 0.5))
     m = t.pool.add_diffuse(tx)
@@ -63,7 +64,7 @@ def _scenes():
     yield "coincident", t
 
 
-@pytest.mark.parametrize("name", ["randomBouncing", "grid3", "10k", "three", "one", "coincident"])
+@pytest.mark.parametrize("name", ["randomBouncing", "grid3", "10k", "three", "one", "coincident", "mesh"])
 def test_product_builder_equals_oracle_build(built, oracle, name):
     t = dict(_scenes())[name]
     a, b = product_tree(t), oracle_tree(oracle, t)

@@ -1,0 +1,105 @@
+"""The build-defined triangle hittable (BASELINE.json configs[4]; the reference's geom.zig has only spheres, so
+nothing here is pinned by the reference — "parity unpinned").  CPU: mode B (kernel arithmetic) against mode A
+(f64, literal Möller–Trumbore inside the reference's BVH).  GPU: bit-exact against mode B, flat list and BVH."""
+import numpy as np
+import pytest
+
+from helpers import assert_images_equal
+from rayz_amd import capi, tracer
+
+
+def _quad_scene(seed=1):
+    """Two triangles as a floor, one as a tilted mirror, one glass triangle, plus a sphere."""
+    t = tracer.Tracer.init(96, 40.0, 5.0, 0.0, (0.5, 2.0, 5.0), (0, 0.5, 0), (0, 1, 0), seed=seed)
+    P = t.pool
+    a, b = P.add_solid_texture((0.8, 0.8, 0.8)), P.add_solid_texture((0.2, 0.3, 0.7))
+    floor = P.add_diffuse(P.add_checker_texture(0.7, a, b))
+    P.add_triangle((-4, 0, -4), (-4, 0, 4), (4, 0, 4), floor)
+    P.add_triangle((-4, 0, -4), (4, 0, 4), (4, 0, -4), floor)
+    P.add_triangle((-2.5, 0.0, -1.5), (-0.5, 0.0, -2.5), (-1.5, 2.2, -2.0), P.add_metallic(a, 0.02))
+    P.add_triangle((0.8, 0.05, 0.5), (2.2, 0.05, 0.2), (1.5, 1.6, 0.4), P.add_dielectric(1.5))
+    P.add_sphere((0, 0.6, 0), 0.6, P.add_diffuse(P.add_solid_texture((0.8, 0.2, 0.2))))
+    return t
+
+
+def test_mesh_scene_shape(built):
+    t = tracer.triangleMesh(1920, 224, seed=1)
+    i = t.info()
+    assert (i.width, i.height, i.n_triangles, i.n_spheres) == (1920, 1080, 100352, 3)  # config 5: 100k triangles
+    sd = t.scene_desc()
+    assert sd.n_triangles == 100352 and sd.triangles[0].material == 0
+    v = np.array([[list(sd.triangles[k].v0), list(sd.triangles[k].v1), list(sd.triangles[k].v2)] for k in range(0, 100352, 997)])
+    assert v[..., 0].min() >= -5 and v[..., 0].max() <= 5 and 0 <= v[..., 1].min() and v[..., 1].max() <= 0.45
+
+
+def test_mode_b_triangles_agree_with_mode_a(oracle):
+    """Mode A renders triangles with a literal f64 Möller–Trumbore inside the reference's BVH and stream; mode B
+    with the kernel's arithmetic.  Same statistical criterion as for spheres."""
+    spp = 64
+    t = _quad_scene()
+    t.samples_per_px = spp
+    t.set_gpu(render_seed=2)
+    sd, cam = t.scene_desc(), t.camera_desc()
+    b, stb = oracle.render_b(sd, cam, t.params())
+    t.set_gpu(traversal=capi.TRAVERSAL_BVH)
+    b2, stb2 = oracle.render_b(sd, cam, t.params())
+    assert np.array_equal(b, b2) and stb.segments == stb2.segments  # flat list == BVH in mode B
+    pa = t.params()
+    pa.precision, pa.tmin = capi.PRECISION_F64, 1e-10
+    rs = t.rng_state().copy()
+    a, sq, sta = oracle.render_a(sd, cam, pa, rs, want_sumsq=True)
+    var = np.maximum(sq / spp - a ** 2, 0) / spp
+    se = np.sqrt(2 * var.sum()) / a.size
+    assert abs(b.astype(np.float64).mean() - a.mean()) < 4 * se
+    assert abs(stb.segments / stb.primary_rays - sta.segments / sta.primary_rays) < 0.05
+
+
+def _pair(gpu, oracle, t):
+    scene, cam, p = t.scene_desc(), t.camera_desc(), t.params()
+    got, gst = gpu.render_host(scene, cam, p)
+    want, ost = oracle.render_b(scene, cam, p)
+    return got, want, gst, ost
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("trav", [capi.TRAVERSAL_LINEAR, capi.TRAVERSAL_BVH])
+@pytest.mark.parametrize("prec", [capi.PRECISION_F32, capi.PRECISION_F64])
+def test_gpu_triangle_parity(gpu, oracle, trav, prec):
+    t = _quad_scene()
+    t.samples_per_px, t.max_bounces = 16, 12
+    t.set_gpu(render_seed=4, traversal=trav, precision=prec)
+    got, want, gst, ost = _pair(gpu, oracle, t)
+    assert_images_equal(got, want, f"triangles traversal {trav} precision {prec}")
+    assert (gst.segments, gst.sphere_tests, gst.node_tests) == (ost.segments, ost.sphere_tests, ost.node_tests)
+
+
+@pytest.mark.gpu
+def test_gpu_small_mesh_flat_list_and_bvh(gpu, oracle):
+    """A 20x20-quad height field (800 triangles + 3 spheres): flat list and BVH, both bit-exact vs mode B."""
+    t = tracer.triangleMesh(96, 20, seed=1)
+    t.samples_per_px, t.max_bounces = 8, 10
+    imgs = []
+    for trav in (capi.TRAVERSAL_LINEAR, capi.TRAVERSAL_BVH):
+        t.set_gpu(render_seed=3, traversal=trav)
+        got, want, gst, ost = _pair(gpu, oracle, t)
+        assert_images_equal(got, want, f"mesh 20x20 traversal {trav}")
+        assert gst.segments == ost.segments and gst.sphere_tests == ost.sphere_tests
+        imgs.append(got)
+    assert (np.abs(imgs[0] - imgs[1]).max(axis=2) > 0).mean() < 2e-3  # same hits up to grazing box-test cases
+
+
+@pytest.mark.gpu
+def test_gpu_config5_full_size_bvh_spot_pixels(gpu, oracle):
+    """configs[4] geometry in full: 100,352 triangles, 1920x1080; BVH traversal; spp reduced to 16 to bound the
+    test (work per sample is spp-independent).  40 scattered pixels are checked bit for bit against the oracle."""
+    t = tracer.triangleMesh(1920, 224, seed=1)
+    t.samples_per_px = 16
+    t.set_gpu(render_seed=1, traversal=capi.TRAVERSAL_BVH)
+    scene, cam, p = t.scene_desc(), t.camera_desc(), t.params()
+    got, st = gpu.render_host(scene, cam, p)
+    assert got.shape == (1080, 1920, 3) and np.isfinite(got).all()
+    assert st.primary_rays == 1920 * 1080 * 16 and st.node_tests > st.segments
+    rng = np.random.default_rng(5)
+    pix = np.unique(rng.integers(0, 1920 * 1080, 40)).astype(np.uint32)
+    want, _ = oracle.render_b(scene, cam, p, pixels=pix)
+    assert_images_equal(got.reshape(-1, 3)[pix], want, "config 5 spot pixels")
