@@ -8,7 +8,7 @@ test + f64 candidate roots.  One "step" = one full frame (2.12 G pixel-samples),
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: one process per GPU; the frame's rows are dealt to ranks in interleaved 8-row tiles (no data-path
+N > 1: one process per GPU; the frame's rows are dealt to ranks round-robin (row r -> rank r % N; no data-path
 collective while tracing), then ONE RCCL all_gather of the f32 framebuffer tiles per step ("strong" scaling:
 the frame is fixed, per-GPU work shrinks with N).  Rank 0 prints one JSON line.
 """
@@ -222,7 +222,7 @@ def main():
                 "workload": f"randomBouncing grid [-{args.grid},{args.grid}) = {info.n_spheres} spheres "
                             f"({n_static} static, {n_moving} moving), {W}x{H}, {args.spp} spp, {args.bounces} bounces, "
                             f"{args.traversal} traversal, scene seed {args.scene_seed}, render seed {args.render_seed}",
-                "parallelism": f"row-tile shard x{world} + RCCL all_gather" if world > 1 else "1 GPU",
+                "parallelism": f"row-interleaved shard x{world} + one RCCL all_gather per frame" if world > 1 else "1 GPU",
                 "segments_per_sample": frame_segments / samples_per_step,
             },
             "roofline": {

@@ -44,7 +44,7 @@ def _worker(rank, world, port, tile_rows, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,tile_rows", [(2, 8), (2, 3), (3, 4)])
+@pytest.mark.parametrize("world,tile_rows", [(2, 1), (2, 8), (3, 4)])
 def test_row_tile_shard_and_gather_gloo(built, world, tile_rows):
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
@@ -59,4 +59,5 @@ def test_frame_gather_single_rank(built):
     fg = rdist.FrameGather(10, 4, 1, 0, torch.device("cpu"))
     fg.tile.copy_(torch.arange(10 * 4 * 3, dtype=torch.float32).reshape(10, 4, 3))
     assert torch.equal(fg.gather(), fg.tile)
-    assert rdist.max_shard_rows(1080, 8) == 136 and rdist.max_shard_rows(2160, 8) == 272
+    assert rdist.max_shard_rows(1080, 8) == 135 and rdist.max_shard_rows(2160, 8) == 270
+    assert rdist.max_shard_rows(1080, 8, tile_rows=8) == 136
