@@ -85,7 +85,8 @@ template <class R> struct TraceArgs {
     uint32_t width, height, spp, max_bounces;
     uint32_t chunk_spp, chunks_per_px;
     uint32_t tile_rows, shard_index, shard_count, shard_pixels;
-    uint32_t total_items, _pad;
+    uint32_t total_items;
+    uint32_t bvh_keep;       // BVH kernel: keep_active | keep_stepping << 8 (see trace_kernel_bvh)
 };
 
 // ---- small helpers -----------------------------------------------------------------------------
@@ -646,12 +647,12 @@ template <class R> struct Slack;
 template <> struct Slack<float> { static constexpr float v = 1.0f + 4.0f * 1.1920929e-07f; };
 template <> struct Slack<double> { static constexpr double v = 1.0 + 4.0 * 2.220446049250313e-16; };
 
-// One node step of a lane: slab test (AABB.hit, src/hit.zig:70-98, with 1/d hoisted and a 4-ulp slack so that
-// rounding never culls a box the f64 narrow phase would hit), then either descend, test the leaf's ≤ 2 spheres,
-// or follow the skip link.
+// Phase N — one box step of a lane: slab test (AABB.hit, src/hit.zig:70-98, with 1/d hoisted and a 4-ulp slack
+// so that rounding never culls a box the f64 narrow phase would hit).  An inner node that is hit descends
+// (next node in memory); a leaf that is hit is PARKED in `leaf` for phase L; anything else follows the skip link.
 template <class R>
-__device__ __forceinline__ void bvh_step(const DevScene<R>& sc, BvhQuery<R>& q, V<R> o, V<R> d, V<R> ud, R time, R tmin,
-                                         uint32_t& node_tests, uint32_t& sphere_tests) {
+__device__ __forceinline__ void bvh_node_step(const DevScene<R>& sc, BvhQuery<R>& q, uint32_t& leaf, V<R> o, R tmin,
+                                              uint32_t& node_tests) {
     typedef typename VecOf<R>::type r4;
     const r4 a = sc.bvh_nodes[2 * q.idx], b = sc.bvh_nodes[2 * q.idx + 1];
     node_tests++;
@@ -662,58 +663,73 @@ __device__ __forceinline__ void bvh_step(const DevScene<R>& sc, BvhQuery<R>& q, 
     const R t1 = mn(mn(mx(ax, bx), mx(ay, by)), mn(mx(az, bz), q.tbest));
     uint32_t next = bits(a.w);
     if (t1 * Slack<R>::v >= t0) {
-        const uint32_t leaf = bits(b.w);
-        const uint32_t cnt = leaf & 3u, first = leaf >> 4;
-        if (cnt == 0u) next = q.idx + 1u;
-        for (uint32_t k = 0; k < cnt; ++k) {
-            const uint32_t slot = first + k;
-            const r4* rec = sc.bvh_leaf + (size_t)sc.bvh_leaf_stride * slot;
-            const r4 c = rec[0], v = rec[1];
-            sphere_tests++;
-            if ((leaf >> (2u + k)) & 1u) { // triangle
-                const r4 e2 = rec[2];
-                const V<R> v0{c.x, c.y, c.z}, e1{v.x, v.y, v.z}, ee2{e2.x, e2.y, e2.z};
-                tri_accept<R>(tri_filter<R>(v0, e1, ee2, o, d), v0, e1, ee2, o, d, tmin, (int)bits(c.w), q.tbest, q.ibest);
-                continue;
-            }
-            const R disc = reject_disc<R>(fm(v.x, time, c.x - o.x), fm(v.y, time, c.y - o.y), fm(v.z, time, c.z - o.z),
-                                          c.w, ud);
-            if (disc >= R(0)) {
-                const d4 c2 = sc.bvh_sph64[2 * slot], v2 = sc.bvh_sph64[2 * slot + 1];
-                const double dx = d.x, dy = d.y, dz = d.z, tm = time;
-                const double qx = fm(v2.x, tm, c2.x - (double)o.x), qy = fm(v2.y, tm, c2.y - (double)o.y),
-                             qz = fm(v2.z, tm, c2.z - (double)o.z);
-                const double a2 = fm(dz, dz, fm(dy, dy, dx * dx));
-                const double hb2 = fm(dz, qz, fm(dy, qy, dx * qx));
-                const double cc2 = fm(qz, qz, fm(qy, qy, fm(qx, qx, -c2.w)));
-                const double disc2 = fm(-a2, cc2, hb2 * hb2);
-                if (disc2 >= 0.0) {
-                    const double rt = __builtin_sqrt(disc2);
-                    const R t1r = (R)((hb2 - rt) * q.inv_a2), t2r = (R)((hb2 + rt) * q.inv_a2);
-                    const R t = t1r >= tmin ? t1r : t2r;
-                    const int pool = (int)bits(v.w);
-                    if (t >= tmin && (t < q.tbest || (t == q.tbest && pool > q.ibest))) {
-                        q.tbest = t;
-                        q.ibest = pool;
-                    }
-                }
-            }
-        }
+        const uint32_t info = bits(b.w);
+        if ((info & 3u) == 0u) next = q.idx + 1u;
+        else leaf = info;
     }
     q.idx = next;
 }
 
+// Phase L — entry k of a parked leaf: a triangle is decided here (R arithmetic only); a sphere gets the reject
+// test in R and, if its line meets the sphere, is parked as a candidate (slot + 1) for phase C.
+template <class R>
+__device__ __forceinline__ uint32_t bvh_leaf_entry(const DevScene<R>& sc, BvhQuery<R>& q, uint32_t leaf, uint32_t k, V<R> o,
+                                                   V<R> d, V<R> ud, R time, R tmin) {
+    typedef typename VecOf<R>::type r4;
+    const uint32_t slot = (leaf >> 4) + k;
+    const r4* rec = sc.bvh_leaf + (size_t)sc.bvh_leaf_stride * slot;
+    const r4 c = rec[0], v = rec[1];
+    if ((leaf >> (2u + k)) & 1u) { // triangle
+        const r4 e2 = rec[2];
+        const V<R> v0{c.x, c.y, c.z}, e1{v.x, v.y, v.z}, ee2{e2.x, e2.y, e2.z};
+        tri_accept<R>(tri_filter<R>(v0, e1, ee2, o, d), v0, e1, ee2, o, d, tmin, (int)bits(c.w), q.tbest, q.ibest);
+        return 0u;
+    }
+    const R disc = reject_disc<R>(fm(v.x, time, c.x - o.x), fm(v.y, time, c.y - o.y), fm(v.z, time, c.z - o.z), c.w, ud);
+    return disc >= R(0) ? slot + 1u : 0u;
+}
+
+// Phase C — the f64 quadratic of a parked sphere candidate (same arithmetic as narrow_phase()).
+template <class R>
+__device__ __forceinline__ void bvh_candidate(const DevScene<R>& sc, BvhQuery<R>& q, uint32_t slot, V<R> o, V<R> d, R time,
+                                              R tmin) {
+    const d4 c2 = sc.bvh_sph64[2 * slot], v2 = sc.bvh_sph64[2 * slot + 1];
+    const int pool = (int)bits(sc.bvh_leaf[(size_t)sc.bvh_leaf_stride * slot + 1].w);
+    const double dx = d.x, dy = d.y, dz = d.z, tm = time;
+    const double qx = fm(v2.x, tm, c2.x - (double)o.x), qy = fm(v2.y, tm, c2.y - (double)o.y),
+                 qz = fm(v2.z, tm, c2.z - (double)o.z);
+    const double a2 = fm(dz, dz, fm(dy, dy, dx * dx));
+    const double hb2 = fm(dz, qz, fm(dy, qy, dx * qx));
+    const double cc2 = fm(qz, qz, fm(qy, qy, fm(qx, qx, -c2.w)));
+    const double disc2 = fm(-a2, cc2, hb2 * hb2);
+    if (disc2 >= 0.0) {
+        const double rt = __builtin_sqrt(disc2);
+        const R t1r = (R)((hb2 - rt) * q.inv_a2), t2r = (R)((hb2 + rt) * q.inv_a2);
+        const R t = t1r >= tmin ? t1r : t2r;
+        if (t >= tmin && (t < q.tbest || (t == q.tbest && pool > q.ibest))) {
+            q.tbest = t;
+            q.ibest = pool;
+        }
+    }
+}
+
 // ---- persistent trace kernel, BVH traversal ------------------------------------------------------
-// Same work items, queue and summation tree as trace_kernel.  Traversal is per lane (divergent), so lanes
-// finish at different times: the node loop runs while at least kBvhKeepActive/64 of the wave is still
-// walking; when fewer remain, the finished lanes are shaded and refilled (ray regeneration) while the
-// unfinished ones keep their query state and resume — the wave never idles behind one long traversal.
-constexpr int kBvhKeepActive = 40;
+// Same work items, queue and summation tree as trace_kernel.  Traversal is per lane, so the wave's lanes want
+// different code at different times; each ROUND therefore runs three convergent phases instead of one divergent
+// step: (N) box steps until most lanes are parked at a leaf, (L) the parked leaves' reject tests together,
+// (C) the parked sphere candidates' f64 roots together.  The nearest hit (with its tie rule) does not depend on
+// the order in which hittables are examined, so this scheduling changes no result — only how much pruning the
+// shrinking tbest achieves.  When too few lanes still have nodes to visit, the finished lanes are shaded and
+// refilled (ray regeneration) while the others keep their query state and resume.
+constexpr int kBvhKeepActive = 40;   // rounds continue while at least this many lanes still walk
+constexpr int kBvhKeepStepping = 24; // phase N continues while at least this many lanes can take a box step
+                                     // (defaults; TraceArgs::bvh_keep carries the values in use)
 
 template <class R> __global__ __launch_bounds__(256) void trace_kernel_bvh(const TraceArgs<R> A) {
     typedef typename VecOf<R>::type r4;
     const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     const uint32_t n_nodes = A.sc.bvh_n_nodes;
+    const int keep_active = (int)(A.bvh_keep & 0xffu), keep_stepping = (int)((A.bvh_keep >> 8) & 0xffu);
     Pcg32 g{0, 1};
     V<R> o{0, 0, 0}, d{0, 0, 1}, ud{0, 0, 1}, thr{1, 1, 1}, acc{0, 0, 0};
     BvhQuery<R> q;
@@ -771,14 +787,31 @@ template <class R> __global__ __launch_bounds__(256) void trace_kernel_bvh(const
         }
         if (__ballot(alive) == 0ull) break;
 
-        // ---- node loop: runs while enough of the wave is still walking ----
+        // ---- rounds of (N) box steps, (L) leaf tests, (C) candidate roots ----
         const int n_alive = __popcll(__ballot(alive));
         for (;;) {
-            const bool walking = alive && q.idx < n_nodes;
-            const int n_walking = __popcll(__ballot(walking));
+            uint32_t leaf = 0;
+            for (;;) { // phase N
+                const bool can_step = alive && q.idx < n_nodes && leaf == 0u;
+                const int n_can = __popcll(__ballot(can_step));
+                if (n_can == 0) break;
+                if (n_can < keep_stepping && __ballot(leaf != 0u) != 0ull) break;
+                if (can_step) bvh_node_step<R>(A.sc, q, leaf, o, A.tmin, node_tests);
+            }
+            if (__ballot(leaf != 0u) == 0ull) break; // nobody parked: every walking lane ran out of nodes
+            uint32_t cand0 = 0, cand1 = 0;
+            if (leaf != 0u) { // phase L
+                sphere_tests += leaf & 3u;
+                cand0 = bvh_leaf_entry<R>(A.sc, q, leaf, 0u, o, d, ud, time, A.tmin);
+                if ((leaf & 3u) > 1u) cand1 = bvh_leaf_entry<R>(A.sc, q, leaf, 1u, o, d, ud, time, A.tmin);
+            }
+            if (__ballot((cand0 | cand1) != 0u) != 0ull) { // phase C
+                if (cand0 != 0u) bvh_candidate<R>(A.sc, q, cand0 - 1u, o, d, time, A.tmin);
+                if (cand1 != 0u) bvh_candidate<R>(A.sc, q, cand1 - 1u, o, d, time, A.tmin);
+            }
+            const int n_walking = __popcll(__ballot(alive && q.idx < n_nodes));
             if (n_walking == 0) break;
-            if (n_walking < kBvhKeepActive && n_walking < n_alive) break; // finished lanes wait: go shade / refill them
-            if (walking) bvh_step<R>(A.sc, q, o, d, ud, time, A.tmin, node_tests, sphere_tests);
+            if (n_walking < keep_active && n_walking < n_alive) break; // finished lanes wait: go shade / refill them
         }
 
         // ---- shade lanes whose query is complete ----

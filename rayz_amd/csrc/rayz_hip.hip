@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -462,6 +463,12 @@ int render_impl(RayzScene* s, SceneBuffers<R>& b, const RayzCameraDesc* cam, con
     A.shard_count = p->shard_count ? p->shard_count : 1u;
     A.shard_pixels = (uint32_t)shard_pixels64;
     A.total_items = (uint32_t)items64;
+    {
+        // scheduling thresholds of the BVH kernel (no effect on results); RAYZ_BVH_KEEP="active,stepping" overrides
+        unsigned ka = kBvhKeepActive, ks = kBvhKeepStepping;
+        if (const char* e = std::getenv("RAYZ_BVH_KEEP")) std::sscanf(e, "%u,%u", &ka, &ks);
+        A.bvh_keep = (ka & 0xffu) | ((ks & 0xffu) << 8);
+    }
 
     int blocks_per_cu = 0;
     if (use_bvh) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, trace_kernel_bvh<R>, 256, 0));

@@ -127,6 +127,15 @@ def test_oracle_bvh_traversal_equals_flat_list(oracle):
 
 
 # ---- GPU ----------------------------------------------------------------------------------------------
+def _check_counters(gst, ost):
+    """Segments are exact.  Box / primitive test counts are work done, not results: the GPU parks leaves and
+    candidates and examines them a phase later, so its shrinking tbest prunes a little less than the oracle's
+    immediate evaluation — never fewer tests, and within a modest factor."""
+    assert gst.segments == ost.segments
+    assert ost.node_tests <= gst.node_tests <= 1.35 * ost.node_tests + 64
+    assert ost.sphere_tests <= gst.sphere_tests <= 1.5 * ost.sphere_tests + 64
+
+
 def _pair(gpu, oracle, t):
     scene, cam, p = t.scene_desc(), t.camera_desc(), t.params()
     got, gst = gpu.render_host(scene, cam, p)
@@ -142,7 +151,7 @@ def test_gpu_bvh_parity_random_bouncing(gpu, oracle, prec):
     t.set_gpu(render_seed=5, traversal=capi.TRAVERSAL_BVH, precision=prec)
     got, want, gst, ost = _pair(gpu, oracle, t)
     assert_images_equal(got, want, f"BVH randomBouncing precision {prec}")
-    assert (gst.segments, gst.node_tests, gst.sphere_tests) == (ost.segments, ost.node_tests, ost.sphere_tests)
+    _check_counters(gst, ost)
 
 
 @pytest.mark.gpu
@@ -152,7 +161,7 @@ def test_gpu_bvh_parity_10k_and_equals_flat_list(gpu, oracle):
     t.set_gpu(render_seed=1, traversal=capi.TRAVERSAL_BVH)
     got, want, gst, ost = _pair(gpu, oracle, t)
     assert_images_equal(got, want, "BVH 10k spheres")
-    assert (gst.segments, gst.node_tests, gst.sphere_tests) == (ost.segments, ost.node_tests, ost.sphere_tests)
+    _check_counters(gst, ost)
     t.set_gpu(traversal=capi.TRAVERSAL_LINEAR)
     flat, fst = gpu.render_host(t.scene_desc(), t.camera_desc(), t.params())
     # same nearest hits up to measure-zero grazing cases of the box test: allow a handful of differing pixels
@@ -168,7 +177,7 @@ def test_gpu_bvh_edge_cases(gpu, oracle):
         t.set_gpu(render_seed=2, traversal=capi.TRAVERSAL_BVH)
         got, want, gst, ost = _pair(gpu, oracle, t)
         assert_images_equal(got, want, f"BVH {name}")
-        assert gst.node_tests == ost.node_tests
+        _check_counters(gst, ost)
     # empty pool: no tree at all, background only
     t = tracer.Tracer.init(48, 40.0, 1.0, 0.0, (0, 0, 0), (0, 0.3, -1), (0, 1, 0), seed=1)
     t.samples_per_px = 2

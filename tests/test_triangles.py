@@ -54,6 +54,18 @@ def test_mode_b_triangles_agree_with_mode_a(oracle):
     assert abs(stb.segments / stb.primary_rays - sta.segments / sta.primary_rays) < 0.05
 
 
+def _check_counters(gst, ost):
+    """Segments are exact.  Box / primitive test counts are work done, not results: the GPU parks leaves and
+    candidates and examines them a phase later, so its shrinking tbest prunes a little less than the oracle's
+    immediate evaluation — never fewer tests, and within a modest factor."""
+    assert gst.segments == ost.segments
+    if ost.node_tests == 0:  # flat list: every hittable, every segment
+        assert (gst.node_tests, gst.sphere_tests) == (0, ost.sphere_tests)
+        return
+    assert ost.node_tests <= gst.node_tests <= 1.35 * ost.node_tests + 64
+    assert ost.sphere_tests <= gst.sphere_tests <= 1.5 * ost.sphere_tests + 64
+
+
 def _pair(gpu, oracle, t):
     scene, cam, p = t.scene_desc(), t.camera_desc(), t.params()
     got, gst = gpu.render_host(scene, cam, p)
@@ -70,7 +82,7 @@ def test_gpu_triangle_parity(gpu, oracle, trav, prec):
     t.set_gpu(render_seed=4, traversal=trav, precision=prec)
     got, want, gst, ost = _pair(gpu, oracle, t)
     assert_images_equal(got, want, f"triangles traversal {trav} precision {prec}")
-    assert (gst.segments, gst.sphere_tests, gst.node_tests) == (ost.segments, ost.sphere_tests, ost.node_tests)
+    _check_counters(gst, ost)
 
 
 @pytest.mark.gpu
@@ -83,7 +95,7 @@ def test_gpu_small_mesh_flat_list_and_bvh(gpu, oracle):
         t.set_gpu(render_seed=3, traversal=trav)
         got, want, gst, ost = _pair(gpu, oracle, t)
         assert_images_equal(got, want, f"mesh 20x20 traversal {trav}")
-        assert gst.segments == ost.segments and gst.sphere_tests == ost.sphere_tests
+        _check_counters(gst, ost)
         imgs.append(got)
     assert (np.abs(imgs[0] - imgs[1]).max(axis=2) > 0).mean() < 2e-3  # same hits up to grazing box-test cases
 
