@@ -63,11 +63,14 @@ template <class R> struct DevScene {
     const r4* tri;           // [3 * (nt_pad + kTriGroup)]
     uint32_t nt_pad, n_triangles;
     // BVH traversal (RAYZ_TRAVERSAL_BVH): the reference's tree in depth-first pre-order, DESIGN.md §6
-    const r4* bvh_nodes;     // [2 * n_nodes] {lo, bits(skip)}, {hi, bits(first << 4 | type1 << 3 | type0 << 2 | count)}
+    const r4* bvh_nodes;     // [4 * n_inner] per INNER node, its two children's boxes (one 64-B fetch, two slab tests):
+                             //   {L.lo, bits(L.id)}, {L.hi, bits(L.leaf)}, {R.lo, bits(R.id)}, {R.hi, bits(R.leaf)}
+                             //   id = the child's inner-node index; leaf = first << 4 | type1 << 3 | type0 << 2 | count
+                             //   (0 for an inner child)
     const r4* bvh_leaf;      // [stride * slots] leaf order.  sphere: {c, r²}, {v, bits(hittable)};
                              //                  triangle: {v0, bits(hittable)}, {e1, 0}, {e2, 0}
     const d4* bvh_sph64;     // [2 * slots] leaf order, sphere slots only: {c, r²}, {v, 0}
-    uint32_t bvh_n_nodes, bvh_leaf_stride;
+    uint32_t bvh_n_nodes, bvh_leaf_stride; // bvh_n_nodes = number of inner-node records (0: empty pool)
 };
 
 template <class R> struct DevCamera {
@@ -624,50 +627,96 @@ template <class R> __global__ __launch_bounds__(256) void trace_kernel(const Tra
     if (lane == 0) atomicAdd(&A.counters[1], tot);
 }
 
-// ---- BVH traversal (src/hit.zig:181-216, recursion → skip links) -----------------------------------
-// Per-lane state of one nearest-hit query over the flattened tree.
+// ---- BVH traversal (src/hit.zig:181-216) ---------------------------------------------------------------
+// The reference recurses left-then-right with a shrinking tmax.  Here each lane walks the same tree with a small
+// stack (LDS) and visits the NEARER child first; the nearest hit and its tie rule do not depend on visiting
+// order, so the result is the reference's.  Per-lane state of one query:
+constexpr int kBvhStackDepth = 28;            // ≥ tree depth: median split gives ceil(log2(n / 2)) + 1 (n ≤ 2^27)
+constexpr uint32_t kBvhDone = 0xffffffffu;    // cursor: nothing left to visit
+constexpr uint32_t kBvhLeafFlag = 0x80000000u; // stack entry is a parked-leaf descriptor, not an inner index
+
 template <class R> struct BvhQuery {
     V<R> inv;       // 1 / d per component
     double inv_a2;  // 1 / (d·d) in f64 for the narrow phase
     R tbest;
-    int ibest;      // pool index
-    uint32_t idx;   // next node; >= n_nodes: done
+    int ibest;      // hittable index
+    uint32_t cur;   // inner node to visit next, or kBvhDone
+    uint32_t sp;    // stack height
 };
 
-template <class R> __device__ __forceinline__ void bvh_begin(BvhQuery<R>& q, V<R> d) {
+template <class R> __device__ __forceinline__ void bvh_begin(BvhQuery<R>& q, V<R> d, uint32_t n_inner) {
     q.inv = {R(1) / d.x, R(1) / d.y, R(1) / d.z};
     const double ddx = d.x, ddy = d.y, ddz = d.z;
     q.inv_a2 = 1.0 / fm(ddz, ddz, fm(ddy, ddy, ddx * ddx));
     q.tbest = (R)__builtin_inff();
     q.ibest = -1;
-    q.idx = 0;
+    q.cur = n_inner ? 0u : kBvhDone;
+    q.sp = 0;
 }
 
 template <class R> struct Slack;
 template <> struct Slack<float> { static constexpr float v = 1.0f + 4.0f * 1.1920929e-07f; };
 template <> struct Slack<double> { static constexpr double v = 1.0 + 4.0 * 2.220446049250313e-16; };
 
-// Phase N — one box step of a lane: slab test (AABB.hit, src/hit.zig:70-98, with 1/d hoisted and a 4-ulp slack
-// so that rounding never culls a box the f64 narrow phase would hit).  An inner node that is hit descends
-// (next node in memory); a leaf that is hit is PARKED in `leaf` for phase L; anything else follows the skip link.
+// Slab test (AABB.hit, src/hit.zig:70-98) with 1/d hoisted and a 4-ulp slack, so that rounding never culls a
+// box the f64 narrow phase would hit.  Returns the entry distance through `t0`.
+template <class R>
+__device__ __forceinline__ bool bvh_box_hit(typename VecOf<R>::type lo, typename VecOf<R>::type hi, const BvhQuery<R>& q,
+                                            V<R> o, R tmin, R& t0) {
+    const R ax = (lo.x - o.x) * q.inv.x, bx = (hi.x - o.x) * q.inv.x;
+    const R ay = (lo.y - o.y) * q.inv.y, by = (hi.y - o.y) * q.inv.y;
+    const R az = (lo.z - o.z) * q.inv.z, bz = (hi.z - o.z) * q.inv.z;
+    t0 = mx(mx(mn(ax, bx), mn(ay, by)), mx(mn(az, bz), tmin));
+    const R t1 = mn(mn(mx(ax, bx), mx(ay, by)), mn(mx(az, bz), q.tbest));
+    return t1 * Slack<R>::v >= t0;
+}
+
+// Phase N — one step of a lane: fetch an inner node's record, slab-test both children, then
+//   * a hit leaf child is PARKED in `leaf` for phase L (a second hit leaf goes to the stack),
+//   * hit inner children: continue into the nearer, push the farther,
+//   * nothing to continue with: pop.
+// `stack` is this lane's column of the workgroup's LDS stack (entry s at stack[s * 256]).
 template <class R>
 __device__ __forceinline__ void bvh_node_step(const DevScene<R>& sc, BvhQuery<R>& q, uint32_t& leaf, V<R> o, R tmin,
-                                              uint32_t& node_tests) {
+                                              uint32_t* stack, uint32_t& node_tests) {
     typedef typename VecOf<R>::type r4;
-    const r4 a = sc.bvh_nodes[2 * q.idx], b = sc.bvh_nodes[2 * q.idx + 1];
-    node_tests++;
-    const R ax = (a.x - o.x) * q.inv.x, bx = (b.x - o.x) * q.inv.x;
-    const R ay = (a.y - o.y) * q.inv.y, by = (b.y - o.y) * q.inv.y;
-    const R az = (a.z - o.z) * q.inv.z, bz = (b.z - o.z) * q.inv.z;
-    const R t0 = mx(mx(mn(ax, bx), mn(ay, by)), mx(mn(az, bz), tmin));
-    const R t1 = mn(mn(mx(ax, bx), mx(ay, by)), mn(mx(az, bz), q.tbest));
-    uint32_t next = bits(a.w);
-    if (t1 * Slack<R>::v >= t0) {
-        const uint32_t info = bits(b.w);
-        if ((info & 3u) == 0u) next = q.idx + 1u;
-        else leaf = info;
+    const r4* p = sc.bvh_nodes + 4 * (size_t)q.cur;
+    const r4 llo = p[0], lhi = p[1], rlo = p[2], rhi = p[3];
+    node_tests += 2;
+    R tl, tr;
+    const bool hl = bvh_box_hit<R>(llo, lhi, q, o, tmin, tl), hr = bvh_box_hit<R>(rlo, rhi, q, o, tmin, tr);
+    const uint32_t lleaf = bits(lhi.w), rleaf = bits(rhi.w);
+    // inner children to continue with (kBvhDone = none), nearer first
+    uint32_t near = (hl && lleaf == 0u) ? bits(llo.w) : kBvhDone;
+    uint32_t far = (hr && rleaf == 0u) ? bits(rlo.w) : kBvhDone;
+    if (far != kBvhDone && (near == kBvhDone || tr < tl)) {
+        const uint32_t t = near;
+        near = far;
+        far = t;
     }
-    q.idx = next;
+    if (far != kBvhDone) stack[256 * q.sp++] = far;
+    // leaf children
+    const uint32_t l0 = (hl && lleaf != 0u) ? lleaf : 0u, l1 = (hr && rleaf != 0u) ? rleaf : 0u;
+    if (l0 != 0u && l1 != 0u) { // both: test one now, keep the other on the stack
+        stack[256 * q.sp++] = l1 | kBvhLeafFlag;
+        leaf = l0;
+    } else if ((l0 | l1) != 0u) {
+        leaf = l0 | l1;
+    }
+    if (near != kBvhDone && leaf != 0u) { // cannot walk on while a leaf is parked: defer the inner child too
+        stack[256 * q.sp++] = near;
+        near = kBvhDone;
+    }
+    q.cur = near;
+}
+
+// Pop until an inner node is found (→ q.cur) or a leaf descriptor is found (→ parked in `leaf`) or the stack is empty.
+template <class R> __device__ __forceinline__ void bvh_pop(BvhQuery<R>& q, uint32_t& leaf, const uint32_t* stack) {
+    if (q.sp != 0u) {
+        const uint32_t e = stack[256 * --q.sp];
+        if (e & kBvhLeafFlag) leaf = e & ~kBvhLeafFlag;
+        else q.cur = e;
+    }
 }
 
 // Phase L — entry k of a parked leaf: a triangle is decided here (R arithmetic only); a sphere gets the reject
@@ -721,11 +770,11 @@ __device__ __forceinline__ void bvh_candidate(const DevScene<R>& sc, BvhQuery<R>
 // the order in which hittables are examined, so this scheduling changes no result — only how much pruning the
 // shrinking tbest achieves.  When too few lanes still have nodes to visit, the finished lanes are shaded and
 // refilled (ray regeneration) while the others keep their query state and resume.
-constexpr int kBvhKeepActive = 40;   // rounds continue while at least this many lanes still walk
-constexpr int kBvhKeepStepping = 24; // phase N continues while at least this many lanes can take a box step
+constexpr int kBvhKeepActive = 24;   // rounds continue while at least this many lanes still walk
+constexpr int kBvhKeepStepping = 12; // phase N continues while at least this many lanes can take a box step
                                      // (defaults; TraceArgs::bvh_keep carries the values in use)
 
-template <class R> __global__ __launch_bounds__(256) void trace_kernel_bvh(const TraceArgs<R> A) {
+template <class R> __global__ __launch_bounds__(256, 5) void trace_kernel_bvh(const TraceArgs<R> A) {
     typedef typename VecOf<R>::type r4;
     const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     const uint32_t n_nodes = A.sc.bvh_n_nodes;
@@ -737,7 +786,10 @@ template <class R> __global__ __launch_bounds__(256) void trace_kernel_bvh(const
     q.inv_a2 = 1.0;
     q.tbest = R(0);
     q.ibest = -1;
-    q.idx = n_nodes;
+    q.cur = kBvhDone;
+    q.sp = 0;
+    __shared__ uint32_t lds_stack[kBvhStackDepth * 256];
+    uint32_t* stack = lds_stack + threadIdx.x; // entry s of this lane at stack[256 * s]: conflict-free for any mix of s
     R time = 0;
     uint32_t item = 0, px = 0, py = 0, s_cur = 0, s_end = 0, seg = 0, nseg = 0, node_tests = 0, sphere_tests = 0;
     bool has_item = false, alive = false;
@@ -783,7 +835,7 @@ template <class R> __global__ __launch_bounds__(256) void trace_kernel_bvh(const
             s_cur++;
             alive = true;
             ud = unit(d);
-            bvh_begin<R>(q, d);
+            bvh_begin<R>(q, d, n_nodes);
         }
         if (__ballot(alive) == 0ull) break;
 
@@ -792,11 +844,13 @@ template <class R> __global__ __launch_bounds__(256) void trace_kernel_bvh(const
         for (;;) {
             uint32_t leaf = 0;
             for (;;) { // phase N
-                const bool can_step = alive && q.idx < n_nodes && leaf == 0u;
+                // a lane with nothing in hand takes its next entry off the stack (an inner node, or a parked leaf)
+                if (alive && leaf == 0u && q.cur == kBvhDone) bvh_pop<R>(q, leaf, stack);
+                const bool can_step = alive && q.cur != kBvhDone && leaf == 0u;
                 const int n_can = __popcll(__ballot(can_step));
                 if (n_can == 0) break;
                 if (n_can < keep_stepping && __ballot(leaf != 0u) != 0ull) break;
-                if (can_step) bvh_node_step<R>(A.sc, q, leaf, o, A.tmin, node_tests);
+                if (can_step) bvh_node_step<R>(A.sc, q, leaf, o, A.tmin, stack, node_tests);
             }
             if (__ballot(leaf != 0u) == 0ull) break; // nobody parked: every walking lane ran out of nodes
             uint32_t cand0 = 0, cand1 = 0;
@@ -809,13 +863,13 @@ template <class R> __global__ __launch_bounds__(256) void trace_kernel_bvh(const
                 if (cand0 != 0u) bvh_candidate<R>(A.sc, q, cand0 - 1u, o, d, time, A.tmin);
                 if (cand1 != 0u) bvh_candidate<R>(A.sc, q, cand1 - 1u, o, d, time, A.tmin);
             }
-            const int n_walking = __popcll(__ballot(alive && q.idx < n_nodes));
+            const int n_walking = __popcll(__ballot(alive && (q.cur != kBvhDone || q.sp != 0u)));
             if (n_walking == 0) break;
             if (n_walking < keep_active && n_walking < n_alive) break; // finished lanes wait: go shade / refill them
         }
 
         // ---- shade lanes whose query is complete ----
-        if (alive && q.idx >= n_nodes) {
+        if (alive && q.cur == kBvhDone && q.sp == 0u) {
             nseg++;
             seg++;
             bool cont = shade<R>(A.sc, g, o, d, ud, time, q.tbest, q.ibest, thr, acc);
@@ -823,7 +877,7 @@ template <class R> __global__ __launch_bounds__(256) void trace_kernel_bvh(const
             alive = cont;
             if (cont) {
                 ud = unit(d);
-                bvh_begin<R>(q, d);
+                bvh_begin<R>(q, d, n_nodes);
             }
         }
     }

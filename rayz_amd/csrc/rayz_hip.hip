@@ -71,7 +71,7 @@ template <class R> struct SceneBuffers {
     r4* tri = nullptr;
     r4* bvh_nodes = nullptr; // BVH traversal only
     r4* bvh_leaf = nullptr;
-    uint32_t nt_pad = 0, bvh_leaf_stride = 2;
+    uint32_t nt_pad = 0, bvh_leaf_stride = 2, bvh_n_inner = 0;
     bool ready = false, bvh_ready = false;
     void release() {
         (void)hipFree(tri);
@@ -290,16 +290,39 @@ template <class R> int upload_bvh(RayzScene* s, SceneBuffers<R>& b) {
     }
     if (b.bvh_ready) return RAYZ_OK;
     b.bvh_leaf_stride = s->triangles.empty() ? 2u : 3u;
+    // one record per INNER node holding its two children's boxes (narrowed outward: never smaller than the f64
+    // box) + where each child leads: an inner index, or a leaf descriptor first << 4 | type1 << 3 | type0 << 2 | count
     std::vector<r4> nodes, leaf;
-    for (const rayz_bvh::FlatNode& n : t.nodes) { // boxes narrowed outward: never smaller than the f64 box
+    std::vector<uint32_t> inner_index(t.nodes.size(), 0u);
+    uint32_t n_inner = 0;
+    for (size_t i = 0; i < t.nodes.size(); ++i)
+        if (t.nodes[i].count == 0) inner_index[i] = n_inner++;
+    auto leaf_info = [&](const rayz_bvh::FlatNode& n) {
         uint32_t info = (n.first << 4) | n.count;
         for (uint32_t k = 0; k < n.count; ++k)
             if (t.order[n.first + k] >= ns) info |= 1u << (2 + k);
+        return info;
+    };
+    auto child = [&](size_t c) {
+        const rayz_bvh::FlatNode& n = t.nodes[c];
+        const bool is_leaf = n.count != 0;
         nodes.push_back(r4{rayz_bvh::roundDown<R>(n.box.lo[0]), rayz_bvh::roundDown<R>(n.box.lo[1]),
-                           rayz_bvh::roundDown<R>(n.box.lo[2]), Bits<R>::from(n.skip)});
+                           rayz_bvh::roundDown<R>(n.box.lo[2]), Bits<R>::from(is_leaf ? 0u : inner_index[c])});
         nodes.push_back(r4{rayz_bvh::roundUp<R>(n.box.hi[0]), rayz_bvh::roundUp<R>(n.box.hi[1]),
-                           rayz_bvh::roundUp<R>(n.box.hi[2]), Bits<R>::from(info)});
+                           rayz_bvh::roundUp<R>(n.box.hi[2]), Bits<R>::from(is_leaf ? leaf_info(n) : 0u)});
+    };
+    if (!t.nodes.empty() && t.nodes[0].count != 0) { // the whole pool fits one leaf: a root record whose two child
+        child(0);                                     // slots both name it (the repeat cannot change the result)
+        child(0);
+        n_inner = 1;
+    } else {
+        for (size_t i = 0; i < t.nodes.size(); ++i)
+            if (t.nodes[i].count == 0) {
+                child(i + 1);                 // left child follows its parent in pre-order
+                child(t.nodes[i + 1].skip);   // right child = where the left subtree ends
+            }
     }
+    b.bvh_n_inner = n_inner;
     for (uint32_t prim : t.order) {
         if (prim < ns) {
             const RayzSphere& q = s->spheres[prim];
@@ -385,6 +408,8 @@ int render_impl(RayzScene* s, SceneBuffers<R>& b, const RayzCameraDesc* cam, con
     if (use_bvh) {
         rc = upload_bvh<R>(s, b);
         if (rc != RAYZ_OK) return rc;
+        if (s->bvh.depth > (uint32_t)kBvhStackDepth)
+            return fail(RAYZ_ERR_BAD_ARG, "BVH depth %u exceeds the traversal stack (%d)", s->bvh.depth, kBvhStackDepth);
     }
 
     const uint32_t rows = rayz_hip_shard_rows(p);
@@ -445,7 +470,7 @@ int render_impl(RayzScene* s, SceneBuffers<R>& b, const RayzCameraDesc* cam, con
     A.sc.bvh_nodes = b.bvh_nodes;
     A.sc.bvh_leaf = b.bvh_leaf;
     A.sc.bvh_sph64 = s->narrow.bvh_sph64;
-    A.sc.bvh_n_nodes = use_bvh ? (uint32_t)s->bvh.nodes.size() : 0u;
+    A.sc.bvh_n_nodes = use_bvh ? b.bvh_n_inner : 0u;
     A.sc.bvh_leaf_stride = b.bvh_leaf_stride;
     fill_camera<R>(cam, A.cam);
     A.partial = (r4*)s->partial;

@@ -128,12 +128,12 @@ def test_oracle_bvh_traversal_equals_flat_list(oracle):
 
 # ---- GPU ----------------------------------------------------------------------------------------------
 def _check_counters(gst, ost):
-    """Segments are exact.  Box / primitive test counts are work done, not results: the GPU parks leaves and
-    candidates and examines them a phase later, so its shrinking tbest prunes a little less than the oracle's
-    immediate evaluation — never fewer tests, and within a modest factor."""
+    """Segments are exact.  Box / primitive test counts are work done, not results: the GPU walks the same tree
+    nearer-child-first with both child boxes tested per visit and parks leaves / candidates for a later phase, the
+    oracle walks it left-then-right like the reference; the nearest hit is order-independent, the pruning is not."""
     assert gst.segments == ost.segments
-    assert ost.node_tests <= gst.node_tests <= 1.35 * ost.node_tests + 64
-    assert ost.sphere_tests <= gst.sphere_tests <= 1.5 * ost.sphere_tests + 64
+    assert 0.3 * ost.node_tests <= gst.node_tests <= 2.0 * ost.node_tests + 64
+    assert 0.3 * ost.sphere_tests <= gst.sphere_tests <= 2.0 * ost.sphere_tests + 64
 
 
 def _pair(gpu, oracle, t):
