@@ -283,6 +283,7 @@ template <class R> struct ScanGroup<R, 0> { // static
         for (int k = 0; k < G; ++k) c[k] = p[k];
     }
     __device__ __forceinline__ void touch() const { asm volatile("" ::"s"(c[0].x)); }
+    template <class T> __device__ __forceinline__ void load_lds(const T* tile, int j, int k) { c[k] = tile->c[j]; }
     __device__ __forceinline__ R disc(int k, V<R> o, V<R> ud, R) const {
         return reject_disc<R>(c[k].x - o.x, c[k].y - o.y, c[k].z - o.z, c[k].w, ud);
     }
@@ -304,6 +305,10 @@ template <class R> struct ScanGroup<R, 1> { // mov-Y
         for (int k = 0; k < G; ++k) c[k] = p[k], vy[k] = q[k];
     }
     __device__ __forceinline__ void touch() const { asm volatile("" ::"s"(c[0].x), "s"(vy[0])); }
+    template <class T> __device__ __forceinline__ void load_lds(const T* tile, int j, int k) {
+        c[k] = tile->c[j];
+        vy[k] = tile->vy[j];
+    }
     __device__ __forceinline__ R disc(int k, V<R> o, V<R> ud, R time) const {
         return reject_disc<R>(c[k].x - o.x, fm(vy[k], time, c[k].y - o.y), c[k].z - o.z, c[k].w, ud);
     }
@@ -323,6 +328,10 @@ template <class R> struct ScanGroup<R, 2> { // mov-G
         for (int k = 0; k < G; ++k) c[k] = p[2 * k], v[k] = p[2 * k + 1];
     }
     __device__ __forceinline__ void touch() const { asm volatile("" ::"s"(c[0].x)); }
+    template <class T> __device__ __forceinline__ void load_lds(const T* tile, int j, int k) {
+        c[k] = tile->c[j];
+        v[k] = tile->v[j];
+    }
     __device__ __forceinline__ R disc(int k, V<R> o, V<R> ud, R time) const {
         return reject_disc<R>(fm(v[k].x, time, c[k].x - o.x), fm(v[k].y, time, c[k].y - o.y),
                               fm(v[k].z, time, c[k].z - o.z), c[k].w, ud);
@@ -621,6 +630,124 @@ template <class R> __global__ __launch_bounds__(256) void trace_kernel(const Tra
         }
     }
     // ---- counters: one atomic per wave ----
+    unsigned long long tot = nseg;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+    if (lane == 0) atomicAdd(&A.counters[1], tot);
+}
+
+// ---- measurement variant: the same flat-list scan with sphere tiles staged through LDS -------------------
+// BASELINE.json's north star suggests "LDS staging of hot sphere tiles".  This kernel does exactly that — the
+// workgroup copies a tile of kLdsTile records into LDS, every lane then reads the records back (all 64 lanes the
+// same address: an LDS broadcast) — with arithmetic identical to trace_kernel, so the two can be compared like
+// for like (RAYZ_FEED=lds selects it; results are bit-identical).  It is NOT the default: DESIGN.md §6 has the
+// measured comparison.  Barriers make the bounce iteration workgroup-synchronous.
+constexpr int kLdsTile = 1024;
+
+template <class R> struct LdsTile {
+    typename VecOf<R>::type c[kLdsTile];
+    typename VecOf<R>::type v[kLdsTile]; // mov-G velocities
+    R vy[kLdsTile];                      // mov-Y velocities (a group's four are one ds_read_b128)
+};
+
+template <class R, int CLS>
+__device__ __forceinline__ void scan_class_lds(const DevScene<R>& sc, int n, LdsTile<R>* tile, V<R> o, V<R> d, V<R> ud,
+                                               R time, double inv_a2, R tmin, R& tbest, int& ibest) {
+    constexpr int G = ScanGroup<R, CLS>::G;
+    for (int base = 0; base < n; base += kLdsTile) {
+        const int m = n - base < kLdsTile ? n - base : kLdsTile;
+        __syncthreads(); // everyone is done reading the previous tile
+        for (int j = (int)threadIdx.x; j < m; j += 256) {
+            if (CLS == 0) tile->c[j] = sc.stat[base + j];
+            if (CLS == 1) {
+                tile->c[j] = sc.movy[base + j];
+                tile->vy[j] = sc.movy_vy[base + j];
+            }
+            if (CLS == 2) {
+                tile->c[j] = sc.movg[2 * (base + j)];
+                tile->v[j] = sc.movg[2 * (base + j) + 1];
+            }
+        }
+        __syncthreads();
+        for (int i = 0; i < m; i += G) {
+            ScanGroup<R, CLS> g;
+#pragma unroll
+            for (int k = 0; k < G; ++k) g.load_lds(tile, i + k, k);
+            test_group<R, CLS>(g, sc, base + i, o, d, ud, time, inv_a2, tmin, tbest, ibest);
+        }
+    }
+}
+
+template <class R> __global__ __launch_bounds__(256) void trace_kernel_lds(const TraceArgs<R> A) {
+    typedef typename VecOf<R>::type r4;
+    __shared__ LdsTile<R> tile;
+    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    Pcg32 g{0, 1};
+    V<R> o{0, 0, 0}, d{0, 0, 1}, thr{1, 1, 1}, acc{0, 0, 0};
+    R time = 0;
+    uint32_t item = 0, px = 0, py = 0, s_cur = 0, s_end = 0, seg = 0, nseg = 0;
+    bool has_item = false, alive = false;
+    bool queue_empty = false; // wave-uniform
+
+    for (;;) {
+        if (!alive && has_item && s_cur == s_end) {
+            A.partial[item] = r4{acc.x, acc.y, acc.z, R(0)};
+            has_item = false;
+        }
+        const bool need = !alive && !has_item && !queue_empty;
+        const unsigned long long need_mask = __ballot(need);
+        if (need_mask != 0ull) {
+            const uint32_t n_need = (uint32_t)__popcll(need_mask);
+            const int leader = __ffsll((long long)need_mask) - 1;
+            unsigned long long base = 0;
+            if ((int)lane == leader) base = atomicAdd(&A.counters[0], (unsigned long long)n_need);
+            base = __shfl(base, leader);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need_mask >> 32),
+                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)need_mask, 0u));
+            const unsigned long long mine = base + rank;
+            if (need && mine < (unsigned long long)A.total_items) {
+                item = (uint32_t)mine;
+                has_item = true;
+                const uint32_t k = item / A.shard_pixels, lp = item - k * A.shard_pixels;
+                const uint32_t lr = lp / A.width;
+                px = lp - lr * A.width;
+                const uint32_t tl = lr / A.tile_rows, within = lr - tl * A.tile_rows;
+                py = (tl * A.shard_count + A.shard_index) * A.tile_rows + within;
+                s_cur = k * A.chunk_spp;
+                s_end = s_cur + A.chunk_spp < A.spp ? s_cur + A.chunk_spp : A.spp;
+                acc = {R(0), R(0), R(0)};
+            }
+            if (base + n_need >= (unsigned long long)A.total_items) queue_empty = true;
+        }
+        if (!alive && has_item) {
+            const unsigned long long pixel_index = (unsigned long long)py * A.width + px;
+            g.seed_path(A.seed, pixel_index * A.spp + s_cur);
+            camera_ray<R>(A.cam, g, px, py, o, d, time);
+            thr = {R(1), R(1), R(1)};
+            seg = 0;
+            s_cur++;
+            alive = true;
+        }
+        if (__syncthreads_or(alive ? 1 : 0) == 0) break; // workgroup-uniform: the tile loops below hold barriers
+
+        const V<R> ud = unit(d);
+        const double ddx = d.x, ddy = d.y, ddz = d.z;
+        const double inv_a2 = 1.0 / fm(ddz, ddz, fm(ddy, ddy, ddx * ddx));
+        R tbest = (R)__builtin_inff();
+        int ibest = -1;
+        scan_class_lds<R, 0>(A.sc, (int)A.sc.ns_pad, &tile, o, d, ud, time, inv_a2, A.tmin, tbest, ibest);
+        scan_class_lds<R, 1>(A.sc, (int)A.sc.ny_pad, &tile, o, d, ud, time, inv_a2, A.tmin, tbest, ibest);
+        scan_class_lds<R, 2>(A.sc, (int)A.sc.ng_pad, &tile, o, d, ud, time, inv_a2, A.tmin, tbest, ibest);
+        scan_triangles<R>(A.sc, o, d, A.tmin, tbest, ibest);
+
+        if (alive) {
+            nseg++;
+            seg++;
+            bool cont = shade<R>(A.sc, g, o, d, ud, time, tbest, ibest, thr, acc);
+            if (seg >= A.max_bounces) cont = false;
+            alive = cont;
+        }
+    }
     unsigned long long tot = nseg;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);

@@ -495,8 +495,12 @@ int render_impl(RayzScene* s, SceneBuffers<R>& b, const RayzCameraDesc* cam, con
         A.bvh_keep = (ka & 0xffu) | ((ks & 0xffu) << 8);
     }
 
+    // measurement variant of the flat-list kernel with LDS-staged sphere tiles (RAYZ_FEED=lds); same results
+    const char* feed = std::getenv("RAYZ_FEED");
+    const bool use_lds = !use_bvh && feed && std::strcmp(feed, "lds") == 0;
     int blocks_per_cu = 0;
-    if (use_bvh) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, trace_kernel_bvh<R>, 256, 0));
+    if (use_lds) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, trace_kernel_lds<R>, 256, 0));
+    else if (use_bvh) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, trace_kernel_bvh<R>, 256, 0));
     else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, trace_kernel<R>, 256, 0));
     if (blocks_per_cu < 1) blocks_per_cu = 1;
     uint64_t grid = (uint64_t)g_num_cu * blocks_per_cu;
@@ -505,7 +509,8 @@ int render_impl(RayzScene* s, SceneBuffers<R>& b, const RayzCameraDesc* cam, con
 
     HIP_TRY(hipMemsetAsync(s->counters, 0, 4 * sizeof(unsigned long long), stream));
     HIP_TRY(hipEventRecord(s->ev0, stream));
-    if (use_bvh) hipLaunchKernelGGL(trace_kernel_bvh<R>, dim3((uint32_t)grid), dim3(256), 0, stream, A);
+    if (use_lds) hipLaunchKernelGGL(trace_kernel_lds<R>, dim3((uint32_t)grid), dim3(256), 0, stream, A);
+    else if (use_bvh) hipLaunchKernelGGL(trace_kernel_bvh<R>, dim3((uint32_t)grid), dim3(256), 0, stream, A);
     else hipLaunchKernelGGL(trace_kernel<R>, dim3((uint32_t)grid), dim3(256), 0, stream, A);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev1, stream));

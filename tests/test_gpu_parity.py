@@ -271,3 +271,15 @@ def test_full_size_config3_spot_pixels_and_counters(gpu, oracle):
     assert_images_equal(got.reshape(-1, 3)[pix], want, "full-size spot pixels")
     # sky rows are brighter than ground rows, and the image is not constant
     assert got[:40].mean() > got[-40:].mean() and got.std() > 0.05
+
+
+def test_lds_tiled_variant_is_bit_identical(gpu, oracle, monkeypatch):
+    """The measurement variant with LDS-staged sphere tiles (RAYZ_FEED=lds) computes the same image
+    as the scalar-feed kernel and the oracle; every stream class and a tile boundary (> 1024 records) included."""
+    monkeypatch.setenv("RAYZ_FEED", "lds")
+    for t in (tracer.randomBouncing(64, -20, 20, seed=42), _custom_scene()):
+        t.samples_per_px, t.max_bounces = 4, 12
+        t.set_gpu(render_seed=8)
+        got, want, gst, ost = _pair(gpu, oracle, t)
+        assert_images_equal(got, want, "LDS-tiled variant")
+        assert gst.segments == ost.segments
