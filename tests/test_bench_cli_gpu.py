@@ -1,0 +1,53 @@
+"""The two entry points a user (and the driver) runs: `bench.py` prints one JSON line with the agreed keys, and
+the `rayz <img_w> [out.ppm]` CLI renders the reference's scene to a P3 PPM (src/rayz.zig:12-43)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_json_contract(gpu):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--width", "96", "--spp", "4", "--grid", "4",
+                        "--steps", "2", "--warmup", "1", "--cpu-seconds", "0.5"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "Msamples/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
+    assert d["higher_is_better"] is True and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and rf["frac"] > 0
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["unit"] == "Msamples/s" and cb["value"] > 0 and cb["sample"]
+    assert d["value"] > 0 and abs(d["value"] - 96 * 54 * 4 * 2 / (d["ms_per_step"] * 2e-3) / 1e6) < 1e-6 * d["value"] + 1e-9
+    assert d["also"]["bvh_traversal"]["value"] > 0
+
+
+def test_cli_renders_reference_scene(gpu, tmp_path):
+    exe = os.path.join(ROOT, "rayz_amd", "host", "rayz")
+    out = tmp_path / "out.ppm"
+    env = dict(os.environ, RAYZ_SEED="7", RAYZ_SPP="3", RAYZ_BOUNCES="6")
+    r = subprocess.run([exe, "96", str(out)], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert "Finished render (" in r.stderr and "rps and" in r.stderr and "us per ray" in r.stderr  # src/rayz.zig:30-34
+    toks = out.read_text().split()
+    assert toks[:4] == ["P3", "96", "54", "255"]
+    px = np.array(toks[4:], dtype=np.int64).reshape(54, 96, 3)
+    assert px.min() >= 0 and px.max() <= 255 and px[:5].mean() > px[-5:].mean()  # sky on top
+    # same seed, same image; stdout form when no file is given
+    r2 = subprocess.run([exe, "96"], capture_output=True, text=True, env=env, timeout=600)
+    assert r2.returncode == 0 and r2.stdout == out.read_text()
