@@ -841,15 +841,30 @@ static PathResult<R> tracePath(const SceneB<R>& sc, const CamB<R>& cam, const Ra
         const double inv_a2 = 1.0 / a2;
         R tbest = inf;
         int ibest = -1;
-        // one sphere: reject test in R, candidates through the f64 quadratic
+        // Reject-test basis: e1 ⟂ ud in the xz-plane, e2 = ud × e1.  The squared
+        // distance from the line to a centre c is p1² + p2² with p1 = c·e1 + k1, p2 = c·e2 + k2; e1.y = 0, so a
+        // y-velocity never enters p1.
+        const R h2 = fm(ud.z, ud.z, ud.x * ud.x);
+        R e1x = R(1), e1z = R(0);
+        if (h2 > R(0)) {
+            const R ih = R(1) / std::sqrt(h2);
+            e1x = ud.z * ih;
+            e1z = -(ud.x * ih);
+        }
+        const R e2x = ud.y * e1z, e2y = fm(ud.z, e1x, -(ud.x * e1z)), e2z = -(ud.y * e1x);
+        const R k1 = -fm(o.z, e1z, o.x * e1x);
+        const R k2 = -fm(o.z, e2z, fm(o.y, e2y, o.x * e2x));
+        const R t1x = time * e1x, t1z = time * e1z, t2x = time * e2x, t2y = time * e2y, t2z = time * e2z;
+        // one sphere: reject test in R (r² − p1² − p2² ≥ 0), candidates through the f64 quadratic
         auto testSphere = [&](const Sph<R>& q) {
-            R ocx = q.c.x - o.x, ocy = q.c.y - o.y, ocz = q.c.z - o.z;
-            if (q.v.x != R(0)) ocx = fm(q.v.x, time, ocx);
-            if (q.v.y != R(0)) ocy = fm(q.v.y, time, ocy);
-            if (q.v.z != R(0)) ocz = fm(q.v.z, time, ocz);
-            const R hbn = fm(ud.z, ocz, fm(ud.y, ocy, ud.x * ocx));
-            const R cc = fm(ocz, ocz, fm(ocy, ocy, fm(ocx, ocx, -q.r2)));
-            const R disc = fm(hbn, hbn, -cc);
+            R p1 = fm(q.c.z, e1z, fm(q.c.x, e1x, k1));
+            if (q.v.x != R(0)) p1 = fm(q.v.x, t1x, p1);
+            if (q.v.z != R(0)) p1 = fm(q.v.z, t1z, p1);
+            R p2 = fm(q.c.z, e2z, fm(q.c.y, e2y, fm(q.c.x, e2x, k2)));
+            if (q.v.x != R(0)) p2 = fm(q.v.x, t2x, p2);
+            if (q.v.y != R(0)) p2 = fm(q.v.y, t2y, p2);
+            if (q.v.z != R(0)) p2 = fm(q.v.z, t2z, p2);
+            const R disc = fm(-p1, p1, fm(-p2, p2, q.r2));
             if (!(disc >= R(0))) return;
             // narrow phase: the reference's quadratic (src/geom.zig:40-58) in f64 on the f64 sphere, for the ray
             // as the kernel holds it; the chosen root is rounded to R before the comparisons

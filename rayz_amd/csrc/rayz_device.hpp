@@ -216,13 +216,39 @@ __device__ __forceinline__ void narrow_phase(const RAYZ_CONSTANT d4* rec, int po
     }
 }
 
-// Reject test of one sphere against the unit direction ud: disc/a = (ud·oc)² − (|oc|² − r²).
-// static: 3 sub + (mul, 2 fma) + 3 fma + 1 fma = 10 VALU; mov-Y +1; mov-G +3.
-template <class R> __device__ __forceinline__ R reject_disc(R ocx, R ocy, R ocz, R r2, V<R> ud) {
-    const R hbn = fm(ud.z, ocz, fm(ud.y, ocy, ud.x * ocx));
-    const R cc = fm(ocz, ocz, fm(ocy, ocy, fm(ocx, ocx, -r2)));
-    return fm(hbn, hbn, -cc);
+// ---- reject test -------------------------------------------------------------------------
+// Per ray: an orthonormal pair (e1, e2) perpendicular to the unit direction ud, with e1 in the xz-plane
+// (e1.y = 0), e2 = ud × e1, and k = −o·e.  The squared distance from the ray's line to a centre c is
+// p1² + p2² with p1 = c·e1 + k1 (2 FMAs; a y-velocity never enters it) and p2 = c·e2 + k2 (3 FMAs), so the test
+// r² − p1² − p2² ≥ 0 costs 7 VALU per static sphere, 8 with a y-velocity, 12 with a general one — against
+// 10 / 11 / 13 for the textbook (ud·oc)² − (|oc|² − r²), and needs no c − o.
+template <class R> struct RayBasis {
+    R e1x, e1z, e2x, e2y, e2z, k1, k2;
+};
+template <class R> __device__ __forceinline__ RayBasis<R> make_basis(V<R> ud, V<R> o) {
+    RayBasis<R> b;
+    const R h2 = fm(ud.z, ud.z, ud.x * ud.x);
+    b.e1x = R(1);
+    b.e1z = R(0);
+    if (h2 > R(0)) {
+        const R ih = R(1) / sq(h2);
+        b.e1x = ud.z * ih;
+        b.e1z = -(ud.x * ih);
+    }
+    b.e2x = ud.y * b.e1z;
+    b.e2y = fm(ud.z, b.e1x, -(ud.x * b.e1z));
+    b.e2z = -(ud.y * b.e1x);
+    b.k1 = -fm(o.z, b.e1z, o.x * b.e1x);
+    b.k2 = -fm(o.z, b.e2z, fm(o.y, b.e2y, o.x * b.e2x));
+    return b;
 }
+template <class R> __device__ __forceinline__ R basis_p1(const RayBasis<R>& b, R cx, R cz) {
+    return fm(cz, b.e1z, fm(cx, b.e1x, b.k1));
+}
+template <class R> __device__ __forceinline__ R basis_p2(const RayBasis<R>& b, R cx, R cy, R cz) {
+    return fm(cz, b.e2z, fm(cy, b.e2y, fm(cx, b.e2x, b.k2)));
+}
+template <class R> __device__ __forceinline__ R basis_disc(R p1, R p2, R r2) { return fm(-p1, p1, fm(-p2, p2, r2)); }
 
 template <class R, int N> __device__ __forceinline__ R max_of(const R (&v)[N]) {
     R m = v[0];
@@ -284,8 +310,8 @@ template <class R> struct ScanGroup<R, 0> { // static
     }
     __device__ __forceinline__ void touch() const { asm volatile("" ::"s"(c[0].x)); }
     template <class T> __device__ __forceinline__ void load_lds(const T* tile, int j, int k) { c[k] = tile->c[j]; }
-    __device__ __forceinline__ R disc(int k, V<R> o, V<R> ud, R) const {
-        return reject_disc<R>(c[k].x - o.x, c[k].y - o.y, c[k].z - o.z, c[k].w, ud);
+    __device__ __forceinline__ R disc(int k, const RayBasis<R>& b, R) const {
+        return basis_disc<R>(basis_p1<R>(b, c[k].x, c[k].z), basis_p2<R>(b, c[k].x, c[k].y, c[k].z), c[k].w);
     }
     static __device__ __forceinline__ const RAYZ_CONSTANT d4* rec64(const DevScene<R>& sc, int i) {
         return (const RAYZ_CONSTANT d4*)sc.stat64 + i;
@@ -309,8 +335,9 @@ template <class R> struct ScanGroup<R, 1> { // mov-Y
         c[k] = tile->c[j];
         vy[k] = tile->vy[j];
     }
-    __device__ __forceinline__ R disc(int k, V<R> o, V<R> ud, R time) const {
-        return reject_disc<R>(c[k].x - o.x, fm(vy[k], time, c[k].y - o.y), c[k].z - o.z, c[k].w, ud);
+    __device__ __forceinline__ R disc(int k, const RayBasis<R>& b, R time) const { // t2y = time · e2.y, hoisted by hipcc
+        return basis_disc<R>(basis_p1<R>(b, c[k].x, c[k].z), fm(vy[k], time * b.e2y, basis_p2<R>(b, c[k].x, c[k].y, c[k].z)),
+                             c[k].w);
     }
     static __device__ __forceinline__ const RAYZ_CONSTANT d4* rec64(const DevScene<R>& sc, int i) {
         return (const RAYZ_CONSTANT d4*)sc.movy64 + 2 * i;
@@ -332,9 +359,11 @@ template <class R> struct ScanGroup<R, 2> { // mov-G
         c[k] = tile->c[j];
         v[k] = tile->v[j];
     }
-    __device__ __forceinline__ R disc(int k, V<R> o, V<R> ud, R time) const {
-        return reject_disc<R>(fm(v[k].x, time, c[k].x - o.x), fm(v[k].y, time, c[k].y - o.y),
-                              fm(v[k].z, time, c[k].z - o.z), c[k].w, ud);
+    __device__ __forceinline__ R disc(int k, const RayBasis<R>& b, R time) const {
+        const R p1 = fm(v[k].z, time * b.e1z, fm(v[k].x, time * b.e1x, basis_p1<R>(b, c[k].x, c[k].z)));
+        const R p2 = fm(v[k].z, time * b.e2z,
+                        fm(v[k].y, time * b.e2y, fm(v[k].x, time * b.e2x, basis_p2<R>(b, c[k].x, c[k].y, c[k].z))));
+        return basis_disc<R>(p1, p2, c[k].w);
     }
     static __device__ __forceinline__ const RAYZ_CONSTANT d4* rec64(const DevScene<R>& sc, int i) {
         return (const RAYZ_CONSTANT d4*)sc.movg64 + 2 * i;
@@ -345,11 +374,11 @@ template <class R> struct ScanGroup<R, 2> { // mov-G
 
 template <class R, int CLS>
 __device__ __forceinline__ void test_group(const ScanGroup<R, CLS>& g, const DevScene<R>& sc, int i, V<R> o, V<R> d,
-                                           V<R> ud, R time, double inv_a2, R tmin, R& tbest, int& ibest) {
+                                           const RayBasis<R>& ud, R time, double inv_a2, R tmin, R& tbest, int& ibest) {
     constexpr int G = ScanGroup<R, CLS>::G;
     R disc[G];
 #pragma unroll
-    for (int k = 0; k < G; ++k) disc[k] = g.disc(k, o, ud, time);
+    for (int k = 0; k < G; ++k) disc[k] = g.disc(k, ud, time);
     if (max_of(disc) >= R(0)) { // any lane, any sphere of the group: rare
         const RAYZ_CONSTANT uint32_t* slot_pool = (const RAYZ_CONSTANT uint32_t*)sc.slot_pool + ScanGroup<R, CLS>::slot0(sc);
 #pragma unroll
@@ -362,7 +391,7 @@ __device__ __forceinline__ void test_group(const ScanGroup<R, CLS>& g, const Dev
 // One velocity class: n is a multiple of 2·G and the stream carries one spare group, so the loads of
 // the next group are always in flight while the current one is tested (ping-pong SGPR sets a / b).
 template <class R, int CLS>
-__device__ __forceinline__ void scan_class(const DevScene<R>& sc, int n, V<R> o, V<R> d, V<R> ud, R time,
+__device__ __forceinline__ void scan_class(const DevScene<R>& sc, int n, V<R> o, V<R> d, const RayBasis<R>& ud, R time,
                                            double inv_a2, R tmin, R& tbest, int& ibest) {
     constexpr int G = ScanGroup<R, CLS>::G;
     if (n == 0) return;
@@ -433,9 +462,10 @@ __device__ __forceinline__ void scan_spheres(const DevScene<R>& sc, V<R> o, V<R>
     const double inv_a2 = 1.0 / fm(ddz, ddz, fm(ddy, ddy, ddx * ddx));
     tbest = (R)__builtin_inff();
     ibest = -1;
-    scan_class<R, 0>(sc, (int)sc.ns_pad, o, d, ud, time, inv_a2, tmin, tbest, ibest);
-    scan_class<R, 1>(sc, (int)sc.ny_pad, o, d, ud, time, inv_a2, tmin, tbest, ibest);
-    scan_class<R, 2>(sc, (int)sc.ng_pad, o, d, ud, time, inv_a2, tmin, tbest, ibest);
+    const RayBasis<R> basis = make_basis<R>(ud, o);
+    scan_class<R, 0>(sc, (int)sc.ns_pad, o, d, basis, time, inv_a2, tmin, tbest, ibest);
+    scan_class<R, 1>(sc, (int)sc.ny_pad, o, d, basis, time, inv_a2, tmin, tbest, ibest);
+    scan_class<R, 2>(sc, (int)sc.ng_pad, o, d, basis, time, inv_a2, tmin, tbest, ibest);
     scan_triangles<R>(sc, o, d, tmin, tbest, ibest);
 }
 
@@ -651,8 +681,8 @@ template <class R> struct LdsTile {
 };
 
 template <class R, int CLS>
-__device__ __forceinline__ void scan_class_lds(const DevScene<R>& sc, int n, LdsTile<R>* tile, V<R> o, V<R> d, V<R> ud,
-                                               R time, double inv_a2, R tmin, R& tbest, int& ibest) {
+__device__ __forceinline__ void scan_class_lds(const DevScene<R>& sc, int n, LdsTile<R>* tile, V<R> o, V<R> d,
+                                               const RayBasis<R>& ud, R time, double inv_a2, R tmin, R& tbest, int& ibest) {
     constexpr int G = ScanGroup<R, CLS>::G;
     for (int base = 0; base < n; base += kLdsTile) {
         const int m = n - base < kLdsTile ? n - base : kLdsTile;
@@ -735,9 +765,10 @@ template <class R> __global__ __launch_bounds__(256) void trace_kernel_lds(const
         const double inv_a2 = 1.0 / fm(ddz, ddz, fm(ddy, ddy, ddx * ddx));
         R tbest = (R)__builtin_inff();
         int ibest = -1;
-        scan_class_lds<R, 0>(A.sc, (int)A.sc.ns_pad, &tile, o, d, ud, time, inv_a2, A.tmin, tbest, ibest);
-        scan_class_lds<R, 1>(A.sc, (int)A.sc.ny_pad, &tile, o, d, ud, time, inv_a2, A.tmin, tbest, ibest);
-        scan_class_lds<R, 2>(A.sc, (int)A.sc.ng_pad, &tile, o, d, ud, time, inv_a2, A.tmin, tbest, ibest);
+        const RayBasis<R> basis = make_basis<R>(ud, o);
+        scan_class_lds<R, 0>(A.sc, (int)A.sc.ns_pad, &tile, o, d, basis, time, inv_a2, A.tmin, tbest, ibest);
+        scan_class_lds<R, 1>(A.sc, (int)A.sc.ny_pad, &tile, o, d, basis, time, inv_a2, A.tmin, tbest, ibest);
+        scan_class_lds<R, 2>(A.sc, (int)A.sc.ng_pad, &tile, o, d, basis, time, inv_a2, A.tmin, tbest, ibest);
         scan_triangles<R>(A.sc, o, d, A.tmin, tbest, ibest);
 
         if (alive) {
@@ -861,8 +892,10 @@ __device__ __forceinline__ uint32_t bvh_leaf_entry(const DevScene<R>& sc, BvhQue
         tri_accept<R>(tri_filter<R>(v0, e1, ee2, o, d), v0, e1, ee2, o, d, tmin, (int)bits(c.w), q.tbest, q.ibest);
         return 0u;
     }
-    const R disc = reject_disc<R>(fm(v.x, time, c.x - o.x), fm(v.y, time, c.y - o.y), fm(v.z, time, c.z - o.z), c.w, ud);
-    return disc >= R(0) ? slot + 1u : 0u;
+    const RayBasis<R> b = make_basis<R>(ud, o); // same filter as the flat list (hipcc shares it between both entries)
+    const R p1 = fm(v.z, time * b.e1z, fm(v.x, time * b.e1x, basis_p1<R>(b, c.x, c.z)));
+    const R p2 = fm(v.z, time * b.e2z, fm(v.y, time * b.e2y, fm(v.x, time * b.e2x, basis_p2<R>(b, c.x, c.y, c.z))));
+    return basis_disc<R>(p1, p2, c.w) >= R(0) ? slot + 1u : 0u;
 }
 
 // Phase C — the f64 quadratic of a parked sphere candidate (same arithmetic as narrow_phase()).
