@@ -28,6 +28,9 @@ PEAK_VALU_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 FLOP/c
 PEAK_HBM_GBPS = 8000.0
 FLOP_PER_TEST_MOVING = 24     # centre-at-time 6 + offset 3 + half_b 5 + c 7 + disc 3
 FLOP_PER_TEST_STATIC = 18
+# what trace_kernel executes per reject test: p1 (2 FMA) + p2 (3 FMA) + r² − p1² − p2² (2 FMA);
+# +1 FMA for a y-velocity; +5 for a general one
+EXEC_FLOP_STATIC, EXEC_FLOP_MOVY, EXEC_FLOP_MOVG = 14, 16, 24
 
 
 def parse_args():
@@ -186,13 +189,20 @@ def main():
             # roofline of the dominant kernel (trace_kernel): algorithmic flops of the reject test per launch.
             # With N GPUs each launch covers 1/N of the frame; rank-mean flops over the slowest rank's time.
             flops = frame_segments / world * (n_static * FLOP_PER_TEST_STATIC + n_moving * FLOP_PER_TEST_MOVING)
+            n_movy = sum(1 for i in range(sd.n_spheres)
+                         if sd.spheres[i].velocity[1] != 0 and sd.spheres[i].velocity[0] == 0 and sd.spheres[i].velocity[2] == 0)
+            executed_flops = frame_segments / world * (n_static * EXEC_FLOP_STATIC + n_movy * EXEC_FLOP_MOVY +
+                                                       (n_moving - n_movy) * EXEC_FLOP_MOVG)
             kernel = "trace_kernel<%s>" % ("double" if args.precision == "f64" else "float")
-            note = ("VALU-bound, not HBM/MFMA (SURVEY.md 8d): algorithmic flops = segments x (18 x static + 24 x moving "
-                    "spheres); the scene (320 KB) is L2/scalar-cache resident")
+            note = ("VALU-bound, not HBM/MFMA (SURVEY.md 8d). achieved/frac use SURVEY 8d's algorithmic flops of the "
+                    "reference's quadratic: segments x (18 x static + 24 x moving spheres); `executed` counts what the "
+                    "kernel's cheaper reject test really issues (14 / 16 / 24 flop per static / y-moving / moving sphere). "
+                    "The scene (320 KB) is L2/scalar-cache resident")
         else:
             st_last = dscene.sync()
             # slab test: 6 sub + 6 mul + 6 min/max + 2 three-way min/max + slack mul = 21 flop; leaf sphere test 24
             flops = (st_last.node_tests * 21 + st_last.sphere_tests * FLOP_PER_TEST_MOVING)
+            executed_flops = flops
             kernel = "trace_kernel_bvh<%s>" % ("double" if args.precision == "f64" else "float")
             note = ("per-lane tree walk: divergence- and latency-bound, priced against the same FP32 vector peak; "
                     "algorithmic flops = 21 x box tests + 24 x leaf sphere tests")
@@ -229,6 +239,8 @@ def main():
                 "bound": "valu_fp32" if args.precision == "f32" else "valu_fp64", "achieved": achieved, "peak": peak,
                 "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                 "kernel": kernel, "kernel_ms": kernel_ms_avg, "note": note,
+                "executed": {"achieved": executed_flops / (kernel_ms_avg * 1e-3) / 1e12,
+                             "frac": executed_flops / (kernel_ms_avg * 1e-3) / 1e12 / peak, "unit": "TFLOP/s"},
                 "hbm": {"algorithmic_bytes": hbm_bytes, "achieved": hbm_bytes / (kernel_ms_avg * 1e-3) / 1e9,
                         "measured_bytes": traffic,
                         "measured": None if traffic is None else traffic / (kernel_ms_avg * 1e-3) / 1e9,

@@ -864,7 +864,7 @@ static PathResult<R> tracePath(const SceneB<R>& sc, const CamB<R>& cam, const Ra
             if (q.v.x != R(0)) p2 = fm(q.v.x, t2x, p2);
             if (q.v.y != R(0)) p2 = fm(q.v.y, t2y, p2);
             if (q.v.z != R(0)) p2 = fm(q.v.z, t2z, p2);
-            const R disc = fm(-p1, p1, fm(-p2, p2, q.r2));
+            const R disc = fm(-p1, p1, fm(-p2, p2, q.r2)); // r² − dist²
             if (!(disc >= R(0))) return;
             // narrow phase: the reference's quadratic (src/geom.zig:40-58) in f64 on the f64 sphere, for the ray
             // as the kernel holds it; the chosen root is rounded to R before the comparisons

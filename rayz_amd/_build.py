@@ -45,8 +45,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
         os.path.join(ROOT, "include", "rayz_hip.h"), os.path.join(ROOT, "include", "rayz_host.h"),
         os.path.abspath(__file__),
     ]
-    if force or _stale(LIB, deps):
-        cmd = [_hipcc(), *HIPFLAGS, "-shared", "-o", LIB, *lib_src]
+    extra = os.environ.get("RAYZ_EXTRA_HIPFLAGS", "").split()  # experiments only (e.g. -DRAYZ_GROUP=8)
+    if force or extra or _stale(LIB, deps):
+        cmd = [_hipcc(), *HIPFLAGS, *extra, "-shared", "-o", LIB, *lib_src]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)

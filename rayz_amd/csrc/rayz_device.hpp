@@ -29,8 +29,11 @@ typedef uint32_t u4 __attribute__((ext_vector_type(4)));
 
 constexpr int kMaxRejectionTries = 64;
 constexpr int kMaxTextureDepth = 8;
-constexpr int kStaticGroup = 4; // spheres per scan group, by velocity class.  A stream is padded to a whole
-constexpr int kMovYGroup = 4;   //   number of group PAIRS plus one spare group, so that the prefetch of the
+#ifndef RAYZ_GROUP
+#define RAYZ_GROUP 4
+#endif
+constexpr int kStaticGroup = RAYZ_GROUP; // spheres per scan group, by velocity class.  A stream is padded to a whole
+constexpr int kMovYGroup = RAYZ_GROUP;   //   number of group PAIRS plus one spare group, so that the prefetch of the
 constexpr int kMovGGroup = 2;   //   next group never leaves the array.
 constexpr int kTriGroup = 2;
 
@@ -309,9 +312,32 @@ template <class R> struct ScanGroup<R, 0> { // static
         for (int k = 0; k < G; ++k) c[k] = p[k];
     }
     __device__ __forceinline__ void touch() const { asm volatile("" ::"s"(c[0].x)); }
+    __device__ __forceinline__ void opaque() {
+#pragma unroll
+        for (int k = 0; k < G; ++k) asm volatile("" : "+s"(c[k].x), "+s"(c[k].y), "+s"(c[k].z), "+s"(c[k].w));
+    }
     template <class T> __device__ __forceinline__ void load_lds(const T* tile, int j, int k) { c[k] = tile->c[j]; }
     __device__ __forceinline__ R disc(int k, const RayBasis<R>& b, R) const {
         return basis_disc<R>(basis_p1<R>(b, c[k].x, c[k].z), basis_p2<R>(b, c[k].x, c[k].y, c[k].z), c[k].w);
+    }
+    // The group's tests computed STAGE BY STAGE: consecutive instructions belong to different spheres, so none
+    // waits for its predecessor's result (the per-test FMA chain is 8 deep; hipcc otherwise emits it back to back).
+    __device__ __forceinline__ void discs(R (&out)[G], const RayBasis<R>& b, R) const {
+        R p1[G], p2[G];
+#pragma unroll
+        for (int k = 0; k < G; ++k) p2[k] = fm(c[k].x, b.e2x, b.k2);
+#pragma unroll
+        for (int k = 0; k < G; ++k) p1[k] = fm(c[k].x, b.e1x, b.k1);
+#pragma unroll
+        for (int k = 0; k < G; ++k) p2[k] = fm(c[k].y, b.e2y, p2[k]);
+#pragma unroll
+        for (int k = 0; k < G; ++k) p1[k] = fm(c[k].z, b.e1z, p1[k]);
+#pragma unroll
+        for (int k = 0; k < G; ++k) p2[k] = fm(c[k].z, b.e2z, p2[k]);
+#pragma unroll
+        for (int k = 0; k < G; ++k) out[k] = fm(-p2[k], p2[k], c[k].w);
+#pragma unroll
+        for (int k = 0; k < G; ++k) out[k] = fm(-p1[k], p1[k], out[k]);
     }
     static __device__ __forceinline__ const RAYZ_CONSTANT d4* rec64(const DevScene<R>& sc, int i) {
         return (const RAYZ_CONSTANT d4*)sc.stat64 + i;
@@ -331,6 +357,10 @@ template <class R> struct ScanGroup<R, 1> { // mov-Y
         for (int k = 0; k < G; ++k) c[k] = p[k], vy[k] = q[k];
     }
     __device__ __forceinline__ void touch() const { asm volatile("" ::"s"(c[0].x), "s"(vy[0])); }
+    __device__ __forceinline__ void opaque() {
+#pragma unroll
+        for (int k = 0; k < G; ++k) asm volatile("" : "+s"(c[k].x), "+s"(c[k].y), "+s"(c[k].z), "+s"(c[k].w), "+s"(vy[k]));
+    }
     template <class T> __device__ __forceinline__ void load_lds(const T* tile, int j, int k) {
         c[k] = tile->c[j];
         vy[k] = tile->vy[j];
@@ -338,6 +368,26 @@ template <class R> struct ScanGroup<R, 1> { // mov-Y
     __device__ __forceinline__ R disc(int k, const RayBasis<R>& b, R time) const { // t2y = time · e2.y, hoisted by hipcc
         return basis_disc<R>(basis_p1<R>(b, c[k].x, c[k].z), fm(vy[k], time * b.e2y, basis_p2<R>(b, c[k].x, c[k].y, c[k].z)),
                              c[k].w);
+    }
+    __device__ __forceinline__ void discs(R (&out)[G], const RayBasis<R>& b, R time) const { // stage by stage (see static)
+        const R t2y = time * b.e2y;
+        R p1[G], p2[G];
+#pragma unroll
+        for (int k = 0; k < G; ++k) p2[k] = fm(c[k].x, b.e2x, b.k2);
+#pragma unroll
+        for (int k = 0; k < G; ++k) p1[k] = fm(c[k].x, b.e1x, b.k1);
+#pragma unroll
+        for (int k = 0; k < G; ++k) p2[k] = fm(c[k].y, b.e2y, p2[k]);
+#pragma unroll
+        for (int k = 0; k < G; ++k) p1[k] = fm(c[k].z, b.e1z, p1[k]);
+#pragma unroll
+        for (int k = 0; k < G; ++k) p2[k] = fm(c[k].z, b.e2z, p2[k]);
+#pragma unroll
+        for (int k = 0; k < G; ++k) p2[k] = fm(vy[k], t2y, p2[k]);
+#pragma unroll
+        for (int k = 0; k < G; ++k) out[k] = fm(-p2[k], p2[k], c[k].w);
+#pragma unroll
+        for (int k = 0; k < G; ++k) out[k] = fm(-p1[k], p1[k], out[k]);
     }
     static __device__ __forceinline__ const RAYZ_CONSTANT d4* rec64(const DevScene<R>& sc, int i) {
         return (const RAYZ_CONSTANT d4*)sc.movy64 + 2 * i;
@@ -355,6 +405,11 @@ template <class R> struct ScanGroup<R, 2> { // mov-G
         for (int k = 0; k < G; ++k) c[k] = p[2 * k], v[k] = p[2 * k + 1];
     }
     __device__ __forceinline__ void touch() const { asm volatile("" ::"s"(c[0].x)); }
+    __device__ __forceinline__ void opaque() {
+#pragma unroll
+        for (int k = 0; k < G; ++k)
+            asm volatile("" : "+s"(c[k].x), "+s"(c[k].y), "+s"(c[k].z), "+s"(c[k].w), "+s"(v[k].x), "+s"(v[k].y), "+s"(v[k].z));
+    }
     template <class T> __device__ __forceinline__ void load_lds(const T* tile, int j, int k) {
         c[k] = tile->c[j];
         v[k] = tile->v[j];
@@ -365,6 +420,10 @@ template <class R> struct ScanGroup<R, 2> { // mov-G
                         fm(v[k].y, time * b.e2y, fm(v[k].x, time * b.e2x, basis_p2<R>(b, c[k].x, c[k].y, c[k].z))));
         return basis_disc<R>(p1, p2, c[k].w);
     }
+    __device__ __forceinline__ void discs(R (&out)[G], const RayBasis<R>& b, R time) const {
+#pragma unroll
+        for (int k = 0; k < G; ++k) out[k] = disc(k, b, time);
+    }
     static __device__ __forceinline__ const RAYZ_CONSTANT d4* rec64(const DevScene<R>& sc, int i) {
         return (const RAYZ_CONSTANT d4*)sc.movg64 + 2 * i;
     }
@@ -372,27 +431,48 @@ template <class R> struct ScanGroup<R, 2> { // mov-G
     static constexpr bool kMoving = true;
 };
 
-template <class R, int CLS>
-__device__ __forceinline__ void test_group(const ScanGroup<R, CLS>& g, const DevScene<R>& sc, int i, V<R> o, V<R> d,
-                                           const RayBasis<R>& ud, R time, double inv_a2, R tmin, R& tbest, int& ibest) {
+// What the scan needs of one ray (one of the NR rays a lane carries).
+template <class R> struct ScanRay {
+    V<R> o, d;
+    R time;
+    RayBasis<R> basis;
+    double inv_a2; // 1 / (d·d) in f64, for the narrow phase
+    R tbest;
+    int ibest;
+};
+
+template <class R, int CLS, int NR>
+__device__ __forceinline__ void test_group(const ScanGroup<R, CLS>& g, const DevScene<R>& sc, int i, ScanRay<R> (&ray)[NR],
+                                           R tmin) {
     constexpr int G = ScanGroup<R, CLS>::G;
-    R disc[G];
+    R disc[NR][G];
+    R m = R(-1);
 #pragma unroll
-    for (int k = 0; k < G; ++k) disc[k] = g.disc(k, ud, time);
-    if (max_of(disc) >= R(0)) { // any lane, any sphere of the group: rare
+    for (int r = 0; r < NR; ++r) {
+        g.discs(disc[r], ray[r].basis, ray[r].time);
+#pragma unroll
+        for (int k = 0; k < G; ++k) m = (r == 0 && k == 0) ? disc[0][0] : mx(m, disc[r][k]);
+    }
+#ifdef RAYZ_DEBUG_NONARROW // timing experiment only (wrong results)
+    if (m >= R(1e30)) {
+#else
+    if (m >= R(0)) { // any lane, any ray, any sphere of the group: rare
+#endif
         const RAYZ_CONSTANT uint32_t* slot_pool = (const RAYZ_CONSTANT uint32_t*)sc.slot_pool + ScanGroup<R, CLS>::slot0(sc);
 #pragma unroll
         for (int k = 0; k < G; ++k)
-            narrow_phase<R, ScanGroup<R, CLS>::kMoving>(ScanGroup<R, CLS>::rec64(sc, i + k), (int)slot_pool[i + k], disc[k],
-                                                        o, d, time, inv_a2, tmin, tbest, ibest);
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+                narrow_phase<R, ScanGroup<R, CLS>::kMoving>(ScanGroup<R, CLS>::rec64(sc, i + k), (int)slot_pool[i + k],
+                                                            disc[r][k], ray[r].o, ray[r].d, ray[r].time, ray[r].inv_a2,
+                                                            tmin, ray[r].tbest, ray[r].ibest);
     }
 }
 
 // One velocity class: n is a multiple of 2·G and the stream carries one spare group, so the loads of
 // the next group are always in flight while the current one is tested (ping-pong SGPR sets a / b).
-template <class R, int CLS>
-__device__ __forceinline__ void scan_class(const DevScene<R>& sc, int n, V<R> o, V<R> d, const RayBasis<R>& ud, R time,
-                                           double inv_a2, R tmin, R& tbest, int& ibest) {
+template <class R, int CLS, int NR>
+__device__ __forceinline__ void scan_class(const DevScene<R>& sc, int n, ScanRay<R> (&ray)[NR], R tmin) {
     constexpr int G = ScanGroup<R, CLS>::G;
     if (n == 0) return;
     ScanGroup<R, CLS> a, b;
@@ -401,14 +481,22 @@ __device__ __forceinline__ void scan_class(const DevScene<R>& sc, int n, V<R> o,
         // Scalar loads return out of order, so a wave can only wait for ALL of them (lgkmcnt(0)).  Order per
         // half: wait for the group loaded one half earlier (touch), issue the next group's loads, then test —
         // the sched_barrier keeps hipcc from sinking the loads below the tests.
+#ifdef RAYZ_DEBUG_NOFEED // timing experiment only: never reload (wrong results); values kept opaque to the compiler
+        if (i == 0) b.load(sc, G);
+        a.opaque();
+        test_group<R, CLS, NR>(a, sc, i, ray, tmin);
+        b.opaque();
+        test_group<R, CLS, NR>(b, sc, i + G, ray, tmin);
+#else
         a.touch();
         b.load(sc, i + G);
         __builtin_amdgcn_sched_barrier(0);
-        test_group<R, CLS>(a, sc, i, o, d, ud, time, inv_a2, tmin, tbest, ibest);
+        test_group<R, CLS, NR>(a, sc, i, ray, tmin);
         b.touch();
         a.load(sc, i + 2 * G);
         __builtin_amdgcn_sched_barrier(0);
-        test_group<R, CLS>(b, sc, i + G, o, d, ud, time, inv_a2, tmin, tbest, ibest);
+        test_group<R, CLS, NR>(b, sc, i + G, ray, tmin);
+#endif
     }
 }
 
@@ -422,21 +510,31 @@ template <class R> struct TriGroup {
         for (int k = 0; k < kTriGroup; ++k) a[k] = p[3 * k], b[k] = p[3 * k + 1], c[k] = p[3 * k + 2];
     }
     __device__ __forceinline__ void touch() const { asm volatile("" ::"s"(a[0].x)); }
-    __device__ __forceinline__ void test(const DevScene<R>& sc, int i, V<R> o, V<R> d, R tmin, R& tbest, int& ibest) const {
-        R f[kTriGroup];
+    template <int NR>
+    __device__ __forceinline__ void test(const DevScene<R>& sc, int i, ScanRay<R> (&ray)[NR], R tmin) const {
+        R f[NR][kTriGroup];
+        R m = R(-1);
 #pragma unroll
-        for (int k = 0; k < kTriGroup; ++k)
-            f[k] = tri_filter<R>(V<R>{a[k].x, a[k].y, a[k].z}, V<R>{b[k].x, b[k].y, b[k].z}, V<R>{c[k].x, c[k].y, c[k].z}, o, d);
-        if (max_of(f) >= R(0)) {
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+            for (int k = 0; k < kTriGroup; ++k) {
+                f[r][k] = tri_filter<R>(V<R>{a[k].x, a[k].y, a[k].z}, V<R>{b[k].x, b[k].y, b[k].z},
+                                        V<R>{c[k].x, c[k].y, c[k].z}, ray[r].o, ray[r].d);
+                m = (r == 0 && k == 0) ? f[0][0] : mx(m, f[r][k]);
+            }
+        if (m >= R(0)) {
 #pragma unroll
             for (int k = 0; k < kTriGroup; ++k)
-                tri_accept<R>(f[k], V<R>{a[k].x, a[k].y, a[k].z}, V<R>{b[k].x, b[k].y, b[k].z},
-                              V<R>{c[k].x, c[k].y, c[k].z}, o, d, tmin, (int)sc.n_spheres + i + k, tbest, ibest);
+#pragma unroll
+                for (int r = 0; r < NR; ++r)
+                    tri_accept<R>(f[r][k], V<R>{a[k].x, a[k].y, a[k].z}, V<R>{b[k].x, b[k].y, b[k].z},
+                                  V<R>{c[k].x, c[k].y, c[k].z}, ray[r].o, ray[r].d, tmin, (int)sc.n_spheres + i + k,
+                                  ray[r].tbest, ray[r].ibest);
         }
     }
 };
-template <class R>
-__device__ __forceinline__ void scan_triangles(const DevScene<R>& sc, V<R> o, V<R> d, R tmin, R& tbest, int& ibest) {
+template <class R, int NR>
+__device__ __forceinline__ void scan_triangles(const DevScene<R>& sc, ScanRay<R> (&ray)[NR], R tmin) {
     const int n = (int)sc.nt_pad;
     if (n == 0) return;
     TriGroup<R> a, b;
@@ -445,28 +543,36 @@ __device__ __forceinline__ void scan_triangles(const DevScene<R>& sc, V<R> o, V<
         a.touch();
         b.load(sc, i + kTriGroup);
         __builtin_amdgcn_sched_barrier(0);
-        a.test(sc, i, o, d, tmin, tbest, ibest);
+        a.template test<NR>(sc, i, ray, tmin);
         b.touch();
         a.load(sc, i + 2 * kTriGroup);
         __builtin_amdgcn_sched_barrier(0);
-        b.test(sc, i + kTriGroup, o, d, tmin, tbest, ibest);
+        b.template test<NR>(sc, i + kTriGroup, ray, tmin);
     }
 }
 
-// ---- the flat-list scan: nearest hit of ray (o, d, time) over every sphere ---------------------
-// Wave-uniform in the sphere index: records arrive by scalar loads and feed the VALU as SGPR operands.
-template <class R>
-__device__ __forceinline__ void scan_spheres(const DevScene<R>& sc, V<R> o, V<R> d, V<R> ud, R time, R tmin, R& tbest,
-                                             int& ibest) {
+// ---- the flat-list scan: nearest hit of each of the lane's NR rays over every hittable -------------------
+// Wave-uniform in the sphere index: records arrive by scalar loads and feed the VALU as SGPR operands.  The
+// scalar data cache delivers only ≈3 B/clk/CU (profiles/r01: busy 100 % at 1 x 64 B per 10.7 clk), which at
+// 20 B per y-moving sphere is ≈10 lane-tests/clk/CU — below the VALU's ≈14.6 with the 8-instruction test.  So a
+// lane carries NR = 2 rays: every fetched record is tested against 128 rays per wave, the scalar feed is
+// halved, and the scan is VALU-bound again.
+template <class R, int NR>
+__device__ __forceinline__ void scan_begin(ScanRay<R>& ray, V<R> o, V<R> d, V<R> ud, R time) {
+    ray.o = o;
+    ray.d = d;
+    ray.time = time;
+    ray.basis = make_basis<R>(ud, o);
     const double ddx = d.x, ddy = d.y, ddz = d.z;
-    const double inv_a2 = 1.0 / fm(ddz, ddz, fm(ddy, ddy, ddx * ddx));
-    tbest = (R)__builtin_inff();
-    ibest = -1;
-    const RayBasis<R> basis = make_basis<R>(ud, o);
-    scan_class<R, 0>(sc, (int)sc.ns_pad, o, d, basis, time, inv_a2, tmin, tbest, ibest);
-    scan_class<R, 1>(sc, (int)sc.ny_pad, o, d, basis, time, inv_a2, tmin, tbest, ibest);
-    scan_class<R, 2>(sc, (int)sc.ng_pad, o, d, basis, time, inv_a2, tmin, tbest, ibest);
-    scan_triangles<R>(sc, o, d, tmin, tbest, ibest);
+    ray.inv_a2 = 1.0 / fm(ddz, ddz, fm(ddy, ddy, ddx * ddx));
+    ray.tbest = (R)__builtin_inff();
+    ray.ibest = -1;
+}
+template <class R, int NR> __device__ __forceinline__ void scan_spheres(const DevScene<R>& sc, ScanRay<R> (&ray)[NR], R tmin) {
+    scan_class<R, 0, NR>(sc, (int)sc.ns_pad, ray, tmin);
+    scan_class<R, 1, NR>(sc, (int)sc.ny_pad, ray, tmin);
+    scan_class<R, 2, NR>(sc, (int)sc.ng_pad, ray, tmin);
+    scan_triangles<R, NR>(sc, ray, tmin);
 }
 
 // ---- shading of one segment: returns false when the path ends ------------------------------------
@@ -586,78 +692,116 @@ __device__ __forceinline__ void camera_ray(const DevCamera<R>& cam, Pcg32& g, ui
     time = uniform<R>(g);
 }
 
-// ---- the persistent trace kernel ---------------------------------------------------------------
-// Work item = (pixel of this shard, chunk of ≤chunk_spp consecutive samples).  Items are numbered
-// chunk-major so that the 64 lanes of a wave start on 64 neighbouring pixels.  Each lane owns one
-// item at a time, runs its paths one after the other, adds their radiance in sample order, and
-// stores the chunk sum to partial[item]; resolve_kernel adds the chunk sums of a pixel in chunk
-// order.  The summation tree is therefore fixed by (spp, chunk_spp) alone — not by the schedule, the
-// grid size or the number of GPUs.
-template <class R> __global__ __launch_bounds__(256) void trace_kernel(const TraceArgs<R> A) {
+// ---- per-path state of one of a lane's rays, and the steps every trace kernel shares ---------------------
+template <class R> struct PathState {
+    Pcg32 g;
+    V<R> o, d, thr, acc;
+    R time;
+    uint32_t item, px, py, s_cur, s_end, seg;
+    bool has_item, alive;
+};
+template <class R> __device__ __forceinline__ void path_init(PathState<R>& p) {
+    p.g = Pcg32{0, 1};
+    p.o = {R(0), R(0), R(0)};
+    p.d = {R(0), R(0), R(1)};
+    p.thr = {R(1), R(1), R(1)};
+    p.acc = {R(0), R(0), R(0)};
+    p.time = R(0);
+    p.item = p.px = p.py = p.s_cur = p.s_end = p.seg = 0;
+    p.has_item = p.alive = false;
+}
+// Retire a finished chunk, pop a new work item for an idle slot (wave-aggregated: ballot → one atomic per wave →
+// mbcnt prefix rank per lane), start the slot's next path.  `queue_empty` is wave-uniform.
+template <class R>
+__device__ __forceinline__ void path_refill(PathState<R>& p, const TraceArgs<R>& A, uint32_t lane, bool& queue_empty) {
     typedef typename VecOf<R>::type r4;
+    if (!p.alive && p.has_item && p.s_cur == p.s_end) {
+        A.partial[p.item] = r4{p.acc.x, p.acc.y, p.acc.z, R(0)};
+        p.has_item = false;
+    }
+    const bool need = !p.alive && !p.has_item && !queue_empty;
+    const unsigned long long need_mask = __ballot(need);
+    if (need_mask != 0ull) { // wave-uniform
+        const uint32_t n_need = (uint32_t)__popcll(need_mask);
+        const int leader = __ffsll((long long)need_mask) - 1;
+        unsigned long long base = 0;
+        if ((int)lane == leader) base = atomicAdd(&A.counters[0], (unsigned long long)n_need);
+        base = __shfl(base, leader);
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need_mask >> 32),
+                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)need_mask, 0u));
+        const unsigned long long mine = base + rank;
+        if (need && mine < (unsigned long long)A.total_items) {
+            p.item = (uint32_t)mine;
+            p.has_item = true;
+            const uint32_t k = p.item / A.shard_pixels, lp = p.item - k * A.shard_pixels;
+            const uint32_t lr = lp / A.width;
+            p.px = lp - lr * A.width;
+            const uint32_t tl = lr / A.tile_rows, within = lr - tl * A.tile_rows;
+            p.py = (tl * A.shard_count + A.shard_index) * A.tile_rows + within;
+            p.s_cur = k * A.chunk_spp;
+            p.s_end = p.s_cur + A.chunk_spp < A.spp ? p.s_cur + A.chunk_spp : A.spp;
+            p.acc = {R(0), R(0), R(0)};
+        }
+        if (base + n_need >= (unsigned long long)A.total_items) queue_empty = true;
+    }
+    if (!p.alive && p.has_item) { // start the next path of this slot's chunk
+        const unsigned long long pixel_index = (unsigned long long)p.py * A.width + p.px;
+        p.g.seed_path(A.seed, pixel_index * A.spp + p.s_cur);
+        camera_ray<R>(A.cam, p.g, p.px, p.py, p.o, p.d, p.time);
+        p.thr = {R(1), R(1), R(1)};
+        p.seg = 0;
+        p.s_cur++;
+        p.alive = true;
+    }
+}
+
+// ---- the persistent trace kernel (flat hit list) ----------------------------------------------------------
+// Work item = (pixel of this shard, chunk of ≤chunk_spp consecutive samples).  Items are numbered chunk-major so
+// that the 64 lanes of a wave start on 64 neighbouring pixels.  Each of a lane's NR slots owns one item at a
+// time, runs its paths one after the other, adds their radiance in sample order, and stores the chunk sum to
+// partial[item]; resolve_kernel adds the chunk sums of a pixel in chunk order.  The summation tree is therefore
+// fixed by (spp, chunk_spp) alone — not by the schedule, the grid size, NR or the number of GPUs.
+template <class R, int NR, bool SYNC> __global__ __launch_bounds__(256) void trace_kernel(const TraceArgs<R> A) {
     const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    Pcg32 g{0, 1};
-    V<R> o{0, 0, 0}, d{0, 0, 1}, thr{1, 1, 1}, acc{0, 0, 0};
-    R time = 0;
-    uint32_t item = 0, px = 0, py = 0, s_cur = 0, s_end = 0, seg = 0, nseg = 0;
-    bool has_item = false, alive = false;
+    PathState<R> p[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) path_init<R>(p[r]);
+    uint32_t nseg = 0;
     bool queue_empty = false; // wave-uniform
 
     for (;;) {
-        // ---- retire finished chunks, refill idle lanes (wave-aggregated queue pop) ----
-        if (!alive && has_item && s_cur == s_end) {
-            A.partial[item] = r4{acc.x, acc.y, acc.z, R(0)};
-            has_item = false;
+        // ---- retire finished chunks, refill idle slots ----
+        bool any = false;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            path_refill<R>(p[r], A, lane, queue_empty);
+            any = any || p[r].alive;
         }
-        const bool need = !alive && !has_item && !queue_empty;
-        const unsigned long long need_mask = __ballot(need);
-        if (need_mask != 0ull) { // wave-uniform
-            const uint32_t n_need = (uint32_t)__popcll(need_mask);
-            unsigned long long base = 0;
-            if (lane == (uint32_t)(__ffsll((long long)need_mask) - 1)) base = atomicAdd(&A.counters[0], (unsigned long long)n_need);
-            base = __shfl(base, __ffsll((long long)need_mask) - 1);
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need_mask >> 32),
-                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)need_mask, 0u));
-            const unsigned long long mine = base + rank;
-            if (need && mine < (unsigned long long)A.total_items) {
-                item = (uint32_t)mine;
-                has_item = true;
-                const uint32_t k = item / A.shard_pixels, lp = item - k * A.shard_pixels;
-                const uint32_t lr = lp / A.width;
-                px = lp - lr * A.width;
-                const uint32_t tl = lr / A.tile_rows, within = lr - tl * A.tile_rows;
-                py = (tl * A.shard_count + A.shard_index) * A.tile_rows + within;
-                s_cur = k * A.chunk_spp;
-                s_end = s_cur + A.chunk_spp < A.spp ? s_cur + A.chunk_spp : A.spp;
-                acc = {R(0), R(0), R(0)};
-            }
-            if (base + n_need >= (unsigned long long)A.total_items) queue_empty = true;
-        }
-        if (!alive && has_item) { // start the next path of this lane's chunk
-            const unsigned long long pixel_index = (unsigned long long)py * A.width + px;
-            g.seed_path(A.seed, pixel_index * A.spp + s_cur);
-            camera_ray<R>(A.cam, g, px, py, o, d, time);
-            thr = {R(1), R(1), R(1)};
-            seg = 0;
-            s_cur++;
-            alive = true;
-        }
-        if (__ballot(alive) == 0ull) break; // queue drained and every lane idle: the wave is done
+        if (SYNC) { // measurement variant: workgroup-synchronous bounce iteration (lockstep waves)
+            if (__syncthreads_or(any ? 1 : 0) == 0) break;
+        } else if (__ballot(any) == 0ull) break; // queue drained and every slot idle: the wave is done
 
-        // ---- nearest hit (full EXEC; idle tail lanes recompute their last ray, results unused) ----
-        R tbest;
-        int ibest;
-        const V<R> ud = unit(d);
-        scan_spheres<R>(A.sc, o, d, ud, time, A.tmin, tbest, ibest);
+        // ---- nearest hit (full EXEC; idle tail slots recompute their last ray, results unused) ----
+        ScanRay<R> ray[NR];
+        V<R> ud[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            ud[r] = unit(p[r].d);
+            scan_begin<R, NR>(ray[r], p[r].o, p[r].d, ud[r], p[r].time);
+        }
+        scan_spheres<R, NR>(A.sc, ray, A.tmin);
 
         // ---- shade ----
-        if (alive) {
-            nseg++;
-            seg++;
-            bool cont = shade<R>(A.sc, g, o, d, ud, time, tbest, ibest, thr, acc);
-            if (seg >= A.max_bounces) cont = false; // depth exhausted → contributes black, src/renderer.zig:104-105
-            alive = cont;
-        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+            if (p[r].alive) {
+                nseg++;
+                p[r].seg++;
+                bool cont = shade<R>(A.sc, p[r].g, p[r].o, p[r].d, ud[r], p[r].time, ray[r].tbest, ray[r].ibest, p[r].thr,
+                                     p[r].acc);
+                if (p[r].seg >= A.max_bounces) cont = false; // depth exhausted → black, src/renderer.zig:104-105
+                p[r].alive = cont;
+            }
     }
     // ---- counters: one atomic per wave ----
     unsigned long long tot = nseg;
@@ -681,8 +825,7 @@ template <class R> struct LdsTile {
 };
 
 template <class R, int CLS>
-__device__ __forceinline__ void scan_class_lds(const DevScene<R>& sc, int n, LdsTile<R>* tile, V<R> o, V<R> d,
-                                               const RayBasis<R>& ud, R time, double inv_a2, R tmin, R& tbest, int& ibest) {
+__device__ __forceinline__ void scan_class_lds(const DevScene<R>& sc, int n, LdsTile<R>* tile, ScanRay<R> (&ray)[1], R tmin) {
     constexpr int G = ScanGroup<R, CLS>::G;
     for (int base = 0; base < n; base += kLdsTile) {
         const int m = n - base < kLdsTile ? n - base : kLdsTile;
@@ -703,80 +846,34 @@ __device__ __forceinline__ void scan_class_lds(const DevScene<R>& sc, int n, Lds
             ScanGroup<R, CLS> g;
 #pragma unroll
             for (int k = 0; k < G; ++k) g.load_lds(tile, i + k, k);
-            test_group<R, CLS>(g, sc, base + i, o, d, ud, time, inv_a2, tmin, tbest, ibest);
+            test_group<R, CLS, 1>(g, sc, base + i, ray, tmin);
         }
     }
 }
 
 template <class R> __global__ __launch_bounds__(256) void trace_kernel_lds(const TraceArgs<R> A) {
-    typedef typename VecOf<R>::type r4;
     __shared__ LdsTile<R> tile;
     const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    Pcg32 g{0, 1};
-    V<R> o{0, 0, 0}, d{0, 0, 1}, thr{1, 1, 1}, acc{0, 0, 0};
-    R time = 0;
-    uint32_t item = 0, px = 0, py = 0, s_cur = 0, s_end = 0, seg = 0, nseg = 0;
-    bool has_item = false, alive = false;
+    PathState<R> p;
+    path_init<R>(p);
+    uint32_t nseg = 0;
     bool queue_empty = false; // wave-uniform
-
     for (;;) {
-        if (!alive && has_item && s_cur == s_end) {
-            A.partial[item] = r4{acc.x, acc.y, acc.z, R(0)};
-            has_item = false;
-        }
-        const bool need = !alive && !has_item && !queue_empty;
-        const unsigned long long need_mask = __ballot(need);
-        if (need_mask != 0ull) {
-            const uint32_t n_need = (uint32_t)__popcll(need_mask);
-            const int leader = __ffsll((long long)need_mask) - 1;
-            unsigned long long base = 0;
-            if ((int)lane == leader) base = atomicAdd(&A.counters[0], (unsigned long long)n_need);
-            base = __shfl(base, leader);
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need_mask >> 32),
-                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)need_mask, 0u));
-            const unsigned long long mine = base + rank;
-            if (need && mine < (unsigned long long)A.total_items) {
-                item = (uint32_t)mine;
-                has_item = true;
-                const uint32_t k = item / A.shard_pixels, lp = item - k * A.shard_pixels;
-                const uint32_t lr = lp / A.width;
-                px = lp - lr * A.width;
-                const uint32_t tl = lr / A.tile_rows, within = lr - tl * A.tile_rows;
-                py = (tl * A.shard_count + A.shard_index) * A.tile_rows + within;
-                s_cur = k * A.chunk_spp;
-                s_end = s_cur + A.chunk_spp < A.spp ? s_cur + A.chunk_spp : A.spp;
-                acc = {R(0), R(0), R(0)};
-            }
-            if (base + n_need >= (unsigned long long)A.total_items) queue_empty = true;
-        }
-        if (!alive && has_item) {
-            const unsigned long long pixel_index = (unsigned long long)py * A.width + px;
-            g.seed_path(A.seed, pixel_index * A.spp + s_cur);
-            camera_ray<R>(A.cam, g, px, py, o, d, time);
-            thr = {R(1), R(1), R(1)};
-            seg = 0;
-            s_cur++;
-            alive = true;
-        }
-        if (__syncthreads_or(alive ? 1 : 0) == 0) break; // workgroup-uniform: the tile loops below hold barriers
-
-        const V<R> ud = unit(d);
-        const double ddx = d.x, ddy = d.y, ddz = d.z;
-        const double inv_a2 = 1.0 / fm(ddz, ddz, fm(ddy, ddy, ddx * ddx));
-        R tbest = (R)__builtin_inff();
-        int ibest = -1;
-        const RayBasis<R> basis = make_basis<R>(ud, o);
-        scan_class_lds<R, 0>(A.sc, (int)A.sc.ns_pad, &tile, o, d, basis, time, inv_a2, A.tmin, tbest, ibest);
-        scan_class_lds<R, 1>(A.sc, (int)A.sc.ny_pad, &tile, o, d, basis, time, inv_a2, A.tmin, tbest, ibest);
-        scan_class_lds<R, 2>(A.sc, (int)A.sc.ng_pad, &tile, o, d, basis, time, inv_a2, A.tmin, tbest, ibest);
-        scan_triangles<R>(A.sc, o, d, A.tmin, tbest, ibest);
-
-        if (alive) {
+        path_refill<R>(p, A, lane, queue_empty);
+        if (__syncthreads_or(p.alive ? 1 : 0) == 0) break; // workgroup-uniform: the tile loops below hold barriers
+        ScanRay<R> ray[1];
+        const V<R> ud = unit(p.d);
+        scan_begin<R, 1>(ray[0], p.o, p.d, ud, p.time);
+        scan_class_lds<R, 0>(A.sc, (int)A.sc.ns_pad, &tile, ray, A.tmin);
+        scan_class_lds<R, 1>(A.sc, (int)A.sc.ny_pad, &tile, ray, A.tmin);
+        scan_class_lds<R, 2>(A.sc, (int)A.sc.ng_pad, &tile, ray, A.tmin);
+        scan_triangles<R, 1>(A.sc, ray, A.tmin);
+        if (p.alive) {
             nseg++;
-            seg++;
-            bool cont = shade<R>(A.sc, g, o, d, ud, time, tbest, ibest, thr, acc);
-            if (seg >= A.max_bounces) cont = false;
-            alive = cont;
+            p.seg++;
+            bool cont = shade<R>(A.sc, p.g, p.o, p.d, ud, p.time, ray[0].tbest, ray[0].ibest, p.thr, p.acc);
+            if (p.seg >= A.max_bounces) cont = false;
+            p.alive = cont;
         }
     }
     unsigned long long tot = nseg;

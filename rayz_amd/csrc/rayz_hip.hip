@@ -498,20 +498,30 @@ int render_impl(RayzScene* s, SceneBuffers<R>& b, const RayzCameraDesc* cam, con
     // measurement variant of the flat-list kernel with LDS-staged sphere tiles (RAYZ_FEED=lds); same results
     const char* feed = std::getenv("RAYZ_FEED");
     const bool use_lds = !use_bvh && feed && std::strcmp(feed, "lds") == 0;
+    // rays per lane of the flat-list kernel: 1.  RAYZ_RAYS=2 (register tiling: every fetched record tested against
+    // two rays per lane) and RAYZ_FEED=sync (a workgroup barrier per bounce iteration) are measurement variants —
+    // neither is faster: the scan is bound by VALU issue cycles, not by the sphere feed
+    int nr = 1;
+    if (const char* e = std::getenv("RAYZ_RAYS")) nr = std::atoi(e) == 2 ? 2 : 1;
+    const bool sync = !use_bvh && feed && std::strcmp(feed, "sync") == 0;
+    const int block = 256;
+    void (*lin)(const TraceArgs<R>) = nr == 2 ? (sync ? trace_kernel<R, 2, true> : trace_kernel<R, 2, false>)
+                                               : (sync ? trace_kernel<R, 1, true> : trace_kernel<R, 1, false>);
     int blocks_per_cu = 0;
     if (use_lds) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, trace_kernel_lds<R>, 256, 0));
     else if (use_bvh) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, trace_kernel_bvh<R>, 256, 0));
-    else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, trace_kernel<R>, 256, 0));
+    else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, lin, 256, 0));
     if (blocks_per_cu < 1) blocks_per_cu = 1;
     uint64_t grid = (uint64_t)g_num_cu * blocks_per_cu;
-    const uint64_t want = (items64 + 255) / 256;
+    const uint64_t per_block = (uint64_t)block * ((use_bvh || use_lds) ? 1 : nr);
+    const uint64_t want = (items64 + per_block - 1) / per_block;
     if (grid > want) grid = want;
 
     HIP_TRY(hipMemsetAsync(s->counters, 0, 4 * sizeof(unsigned long long), stream));
     HIP_TRY(hipEventRecord(s->ev0, stream));
     if (use_lds) hipLaunchKernelGGL(trace_kernel_lds<R>, dim3((uint32_t)grid), dim3(256), 0, stream, A);
     else if (use_bvh) hipLaunchKernelGGL(trace_kernel_bvh<R>, dim3((uint32_t)grid), dim3(256), 0, stream, A);
-    else hipLaunchKernelGGL(trace_kernel<R>, dim3((uint32_t)grid), dim3(256), 0, stream, A);
+    else hipLaunchKernelGGL(lin, dim3((uint32_t)grid), dim3(256), 0, stream, A);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev1, stream));
     hipLaunchKernelGGL(resolve_kernel<R>, dim3((A.shard_pixels + 255) / 256), dim3(256), 0, stream,
