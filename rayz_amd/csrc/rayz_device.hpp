@@ -26,6 +26,8 @@ namespace rayz_dev {
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef double d2 __attribute__((ext_vector_type(2)));
 
 constexpr int kMaxRejectionTries = 64;
 constexpr int kMaxTextureDepth = 8;
@@ -38,20 +40,22 @@ constexpr int kMovGGroup = 2;   //   next group never leaves the array.
 constexpr int kTriGroup = 2;
 
 template <class R> struct VecOf;
-template <> struct VecOf<float> { typedef f4 type; };
-template <> struct VecOf<double> { typedef d4 type; };
+template <> struct VecOf<float> { typedef f4 type; typedef f2 pair; };
+template <> struct VecOf<double> { typedef d4 type; typedef d2 pair; };
 
 // ---- device-resident scene (HBM layout) ------------------------------------------
 // Scan streams, one per velocity class, each padded with never-hit records (r² = -inf):
-//   static  v = 0            stat[i]  = {cx, cy, cz, r²}
-//   mov-Y   v = (0, vy, 0)   movy[i]  = {cx, cy, cz, r²}, movy_vy[i] = vy       (what randomBouncing makes)
+//   static  v = 0            stat: blocks of G = 8 spheres, SoA inside a block: cx[8] cy[8] cz[8] r²[8]
+//   mov-Y   v = (0, vy, 0)   movy: blocks of 8:                                 cx[8] cy[8] cz[8] r²[8] vy[8]
+//                            (what randomBouncing makes)
 //   mov-G   any other v      movg[2i] = {cx, cy, cz, r²}, movg[2i+1] = {vx, vy, vz, 0}
-// A "slot" numbers the records stat | movy | movg in that order.  The f64 copies feed the narrow phase.
+// The block layout puts the same field of two neighbouring spheres in one aligned SGPR pair, which is what a
+// v_pk_fma_f32 takes as a single scalar operand.  A "slot" numbers the records stat | movy | movg
+// in that order.  The f64 copies feed the narrow phase.
 template <class R> struct DevScene {
     typedef typename VecOf<R>::type r4;
-    const r4* stat;
-    const r4* movy;
-    const R* movy_vy;
+    const R* stat;           // [4 * ns_pad + spare block]
+    const R* movy;           // [5 * ny_pad + spare block]
     const r4* movg;
     const d4* stat64;        // [ns_pad]      {cx, cy, cz, r²}          (aliases stat for R = double)
     const d4* movy64;        // [2 * ny_pad]  {cx, cy, cz, r²}, {0, vy, 0, 0}
@@ -302,42 +306,40 @@ __device__ __forceinline__ void tri_accept(R filt, V<R> v0, V<R> e1, V<R> e2, V<
 // reject test of its spheres against 64 rays and sends candidates to the narrow phase.
 template <class R, int CLS> struct ScanGroup;
 
+// The reject tests of a block run two spheres per instruction: each stage is ONE packed FMA (v_pk_fma_f32 for
+// R = float) whose scalar operand is an SGPR PAIR — the same field of two neighbouring spheres.  Measured on
+// gfx950 (tools/ubench): a VALU instruction that reads a different SGPR each time issues at ≈2.75 cycles, not 2,
+// so the 7 scalar reads of a test bound the scalar-FMA form at ≈21 ticks per wave-test; the packed form needs
+// 2.5 pair reads per test and runs at 14.7.  Every half of a packed FMA is an ordinary IEEE FMA: results are
+// bit-identical to the scalar form (and to the oracle).
 template <class R> struct ScanGroup<R, 0> { // static
-    typedef typename VecOf<R>::type r4;
-    static constexpr int G = kStaticGroup;
-    r4 c[G];
+    typedef typename VecOf<R>::pair pr;
+    static constexpr int G = kStaticGroup, H = kStaticGroup / 2;
+    pr cx[H], cy[H], cz[H], r2[H];
     __device__ __forceinline__ void load(const DevScene<R>& sc, int i) {
-        const RAYZ_CONSTANT r4* p = (const RAYZ_CONSTANT r4*)sc.stat + i;
+        const RAYZ_CONSTANT pr* p = (const RAYZ_CONSTANT pr*)((const RAYZ_CONSTANT R*)sc.stat + 4 * i);
 #pragma unroll
-        for (int k = 0; k < G; ++k) c[k] = p[k];
+        for (int q = 0; q < H; ++q) cx[q] = p[q], cy[q] = p[H + q], cz[q] = p[2 * H + q], r2[q] = p[3 * H + q];
     }
-    __device__ __forceinline__ void touch() const { asm volatile("" ::"s"(c[0].x)); }
+    __device__ __forceinline__ void touch() const { asm volatile("" ::"s"(cx[0])); }
     __device__ __forceinline__ void opaque() {
 #pragma unroll
-        for (int k = 0; k < G; ++k) asm volatile("" : "+s"(c[k].x), "+s"(c[k].y), "+s"(c[k].z), "+s"(c[k].w));
+        for (int q = 0; q < H; ++q) asm volatile("" : "+s"(cx[q]), "+s"(cy[q]), "+s"(cz[q]), "+s"(r2[q]));
     }
-    template <class T> __device__ __forceinline__ void load_lds(const T* tile, int j, int k) { c[k] = tile->c[j]; }
-    __device__ __forceinline__ R disc(int k, const RayBasis<R>& b, R) const {
-        return basis_disc<R>(basis_p1<R>(b, c[k].x, c[k].z), basis_p2<R>(b, c[k].x, c[k].y, c[k].z), c[k].w);
-    }
-    // The group's tests computed STAGE BY STAGE: consecutive instructions belong to different spheres, so none
-    // waits for its predecessor's result (the per-test FMA chain is 8 deep; hipcc otherwise emits it back to back).
     __device__ __forceinline__ void discs(R (&out)[G], const RayBasis<R>& b, R) const {
-        R p1[G], p2[G];
+        const pr E1x{b.e1x, b.e1x}, E1z{b.e1z, b.e1z}, E2x{b.e2x, b.e2x}, E2y{b.e2y, b.e2y}, E2z{b.e2z, b.e2z},
+            K1{b.k1, b.k1}, K2{b.k2, b.k2};
 #pragma unroll
-        for (int k = 0; k < G; ++k) p2[k] = fm(c[k].x, b.e2x, b.k2);
-#pragma unroll
-        for (int k = 0; k < G; ++k) p1[k] = fm(c[k].x, b.e1x, b.k1);
-#pragma unroll
-        for (int k = 0; k < G; ++k) p2[k] = fm(c[k].y, b.e2y, p2[k]);
-#pragma unroll
-        for (int k = 0; k < G; ++k) p1[k] = fm(c[k].z, b.e1z, p1[k]);
-#pragma unroll
-        for (int k = 0; k < G; ++k) p2[k] = fm(c[k].z, b.e2z, p2[k]);
-#pragma unroll
-        for (int k = 0; k < G; ++k) out[k] = fm(-p2[k], p2[k], c[k].w);
-#pragma unroll
-        for (int k = 0; k < G; ++k) out[k] = fm(-p1[k], p1[k], out[k]);
+        for (int q = 0; q < H; ++q) {
+            pr p1 = __builtin_elementwise_fma(cx[q], E1x, K1);
+            pr p2 = __builtin_elementwise_fma(cx[q], E2x, K2);
+            p1 = __builtin_elementwise_fma(cz[q], E1z, p1);
+            p2 = __builtin_elementwise_fma(cy[q], E2y, p2);
+            p2 = __builtin_elementwise_fma(cz[q], E2z, p2);
+            const pr d = __builtin_elementwise_fma(-p1, p1, __builtin_elementwise_fma(-p2, p2, r2[q]));
+            out[2 * q] = d.x;
+            out[2 * q + 1] = d.y;
+        }
     }
     static __device__ __forceinline__ const RAYZ_CONSTANT d4* rec64(const DevScene<R>& sc, int i) {
         return (const RAYZ_CONSTANT d4*)sc.stat64 + i;
@@ -346,48 +348,36 @@ template <class R> struct ScanGroup<R, 0> { // static
     static constexpr bool kMoving = false;
 };
 template <class R> struct ScanGroup<R, 1> { // mov-Y
-    typedef typename VecOf<R>::type r4;
-    static constexpr int G = kMovYGroup;
-    r4 c[G];
-    R vy[G];
+    typedef typename VecOf<R>::pair pr;
+    static constexpr int G = kMovYGroup, H = kMovYGroup / 2;
+    pr cx[H], cy[H], cz[H], r2[H], vy[H];
     __device__ __forceinline__ void load(const DevScene<R>& sc, int i) {
-        const RAYZ_CONSTANT r4* p = (const RAYZ_CONSTANT r4*)sc.movy + i;
-        const RAYZ_CONSTANT R* q = (const RAYZ_CONSTANT R*)sc.movy_vy + i;
+        const RAYZ_CONSTANT pr* p = (const RAYZ_CONSTANT pr*)((const RAYZ_CONSTANT R*)sc.movy + 5 * i);
 #pragma unroll
-        for (int k = 0; k < G; ++k) c[k] = p[k], vy[k] = q[k];
+        for (int q = 0; q < H; ++q)
+            cx[q] = p[q], cy[q] = p[H + q], cz[q] = p[2 * H + q], r2[q] = p[3 * H + q], vy[q] = p[4 * H + q];
     }
-    __device__ __forceinline__ void touch() const { asm volatile("" ::"s"(c[0].x), "s"(vy[0])); }
+    __device__ __forceinline__ void touch() const { asm volatile("" ::"s"(cx[0]), "s"(vy[0])); }
     __device__ __forceinline__ void opaque() {
 #pragma unroll
-        for (int k = 0; k < G; ++k) asm volatile("" : "+s"(c[k].x), "+s"(c[k].y), "+s"(c[k].z), "+s"(c[k].w), "+s"(vy[k]));
+        for (int q = 0; q < H; ++q) asm volatile("" : "+s"(cx[q]), "+s"(cy[q]), "+s"(cz[q]), "+s"(r2[q]), "+s"(vy[q]));
     }
-    template <class T> __device__ __forceinline__ void load_lds(const T* tile, int j, int k) {
-        c[k] = tile->c[j];
-        vy[k] = tile->vy[j];
-    }
-    __device__ __forceinline__ R disc(int k, const RayBasis<R>& b, R time) const { // t2y = time · e2.y, hoisted by hipcc
-        return basis_disc<R>(basis_p1<R>(b, c[k].x, c[k].z), fm(vy[k], time * b.e2y, basis_p2<R>(b, c[k].x, c[k].y, c[k].z)),
-                             c[k].w);
-    }
-    __device__ __forceinline__ void discs(R (&out)[G], const RayBasis<R>& b, R time) const { // stage by stage (see static)
+    __device__ __forceinline__ void discs(R (&out)[G], const RayBasis<R>& b, R time) const {
         const R t2y = time * b.e2y;
-        R p1[G], p2[G];
+        const pr E1x{b.e1x, b.e1x}, E1z{b.e1z, b.e1z}, E2x{b.e2x, b.e2x}, E2y{b.e2y, b.e2y}, E2z{b.e2z, b.e2z},
+            K1{b.k1, b.k1}, K2{b.k2, b.k2}, T2y{t2y, t2y};
 #pragma unroll
-        for (int k = 0; k < G; ++k) p2[k] = fm(c[k].x, b.e2x, b.k2);
-#pragma unroll
-        for (int k = 0; k < G; ++k) p1[k] = fm(c[k].x, b.e1x, b.k1);
-#pragma unroll
-        for (int k = 0; k < G; ++k) p2[k] = fm(c[k].y, b.e2y, p2[k]);
-#pragma unroll
-        for (int k = 0; k < G; ++k) p1[k] = fm(c[k].z, b.e1z, p1[k]);
-#pragma unroll
-        for (int k = 0; k < G; ++k) p2[k] = fm(c[k].z, b.e2z, p2[k]);
-#pragma unroll
-        for (int k = 0; k < G; ++k) p2[k] = fm(vy[k], t2y, p2[k]);
-#pragma unroll
-        for (int k = 0; k < G; ++k) out[k] = fm(-p2[k], p2[k], c[k].w);
-#pragma unroll
-        for (int k = 0; k < G; ++k) out[k] = fm(-p1[k], p1[k], out[k]);
+        for (int q = 0; q < H; ++q) {
+            pr p1 = __builtin_elementwise_fma(cx[q], E1x, K1);
+            pr p2 = __builtin_elementwise_fma(cx[q], E2x, K2);
+            p1 = __builtin_elementwise_fma(cz[q], E1z, p1);
+            p2 = __builtin_elementwise_fma(cy[q], E2y, p2);
+            p2 = __builtin_elementwise_fma(cz[q], E2z, p2);
+            p2 = __builtin_elementwise_fma(vy[q], T2y, p2);
+            const pr d = __builtin_elementwise_fma(-p1, p1, __builtin_elementwise_fma(-p2, p2, r2[q]));
+            out[2 * q] = d.x;
+            out[2 * q + 1] = d.y;
+        }
     }
     static __device__ __forceinline__ const RAYZ_CONSTANT d4* rec64(const DevScene<R>& sc, int i) {
         return (const RAYZ_CONSTANT d4*)sc.movy64 + 2 * i;
@@ -409,10 +399,6 @@ template <class R> struct ScanGroup<R, 2> { // mov-G
 #pragma unroll
         for (int k = 0; k < G; ++k)
             asm volatile("" : "+s"(c[k].x), "+s"(c[k].y), "+s"(c[k].z), "+s"(c[k].w), "+s"(v[k].x), "+s"(v[k].y), "+s"(v[k].z));
-    }
-    template <class T> __device__ __forceinline__ void load_lds(const T* tile, int j, int k) {
-        c[k] = tile->c[j];
-        v[k] = tile->v[j];
     }
     __device__ __forceinline__ R disc(int k, const RayBasis<R>& b, R time) const {
         const R p1 = fm(v[k].z, time * b.e1z, fm(v[k].x, time * b.e1x, basis_p1<R>(b, c[k].x, c[k].z)));
@@ -441,62 +427,70 @@ template <class R> struct ScanRay {
     int ibest;
 };
 
+// Reject tests of one group for the lane's NR rays; the running maximum feeds the pair's single branch.
 template <class R, int CLS, int NR>
-__device__ __forceinline__ void test_group(const ScanGroup<R, CLS>& g, const DevScene<R>& sc, int i, ScanRay<R> (&ray)[NR],
-                                           R tmin) {
+__device__ __forceinline__ void group_discs(const ScanGroup<R, CLS>& g, ScanRay<R> (&ray)[NR], R (&disc)[NR][ScanGroup<R, CLS>::G],
+                                            R& m, bool first) {
     constexpr int G = ScanGroup<R, CLS>::G;
-    R disc[NR][G];
-    R m = R(-1);
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         g.discs(disc[r], ray[r].basis, ray[r].time);
 #pragma unroll
-        for (int k = 0; k < G; ++k) m = (r == 0 && k == 0) ? disc[0][0] : mx(m, disc[r][k]);
-    }
-#ifdef RAYZ_DEBUG_NONARROW // timing experiment only (wrong results)
-    if (m >= R(1e30)) {
-#else
-    if (m >= R(0)) { // any lane, any ray, any sphere of the group: rare
-#endif
-        const RAYZ_CONSTANT uint32_t* slot_pool = (const RAYZ_CONSTANT uint32_t*)sc.slot_pool + ScanGroup<R, CLS>::slot0(sc);
-#pragma unroll
-        for (int k = 0; k < G; ++k)
-#pragma unroll
-            for (int r = 0; r < NR; ++r)
-                narrow_phase<R, ScanGroup<R, CLS>::kMoving>(ScanGroup<R, CLS>::rec64(sc, i + k), (int)slot_pool[i + k],
-                                                            disc[r][k], ray[r].o, ray[r].d, ray[r].time, ray[r].inv_a2,
-                                                            tmin, ray[r].tbest, ray[r].ibest);
+        for (int k = 0; k < G; ++k) m = (first && r == 0 && k == 0) ? disc[0][0] : mx(m, disc[r][k]);
     }
 }
+// Narrow phase of one group's candidates (slots i .. i+G-1).
+template <class R, int CLS, int NR>
+__device__ __forceinline__ void group_narrow(const DevScene<R>& sc, int i, ScanRay<R> (&ray)[NR],
+                                             const R (&disc)[NR][ScanGroup<R, CLS>::G], R tmin) {
+    constexpr int G = ScanGroup<R, CLS>::G;
+    const RAYZ_CONSTANT uint32_t* slot_pool = (const RAYZ_CONSTANT uint32_t*)sc.slot_pool + ScanGroup<R, CLS>::slot0(sc);
+#pragma unroll
+    for (int k = 0; k < G; ++k)
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+            narrow_phase<R, ScanGroup<R, CLS>::kMoving>(ScanGroup<R, CLS>::rec64(sc, i + k), (int)slot_pool[i + k], disc[r][k],
+                                                        ray[r].o, ray[r].d, ray[r].time, ray[r].inv_a2, tmin, ray[r].tbest,
+                                                        ray[r].ibest);
+}
 
-// One velocity class: n is a multiple of 2·G and the stream carries one spare group, so the loads of
-// the next group are always in flight while the current one is tested (ping-pong SGPR sets a / b).
+// One velocity class.  n is a multiple of 2·G and the stream carries two spare groups.  Per iteration: wait for
+// the two groups loaded during the previous iteration, test group a and immediately reload its SGPR set with the
+// group after next, the same for b, then ONE reject branch for the 2·G tests.  (Scalar loads return out of
+// order, so a wave can only wait for all of them — lgkmcnt(0) — hence the explicit order; the sched_barriers
+// keep hipcc from sinking the loads.  The branch costs ≈10 cycles of a wave's time: once per 8 tests, not 4.)
 template <class R, int CLS, int NR>
 __device__ __forceinline__ void scan_class(const DevScene<R>& sc, int n, ScanRay<R> (&ray)[NR], R tmin) {
     constexpr int G = ScanGroup<R, CLS>::G;
     if (n == 0) return;
     ScanGroup<R, CLS> a, b;
     a.load(sc, 0);
+    b.load(sc, G);
     for (int i = 0; i < n; i += 2 * G) {
-        // Scalar loads return out of order, so a wave can only wait for ALL of them (lgkmcnt(0)).  Order per
-        // half: wait for the group loaded one half earlier (touch), issue the next group's loads, then test —
-        // the sched_barrier keeps hipcc from sinking the loads below the tests.
+        R da[NR][G], db[NR][G];
+        R m = R(-1);
 #ifdef RAYZ_DEBUG_NOFEED // timing experiment only: never reload (wrong results); values kept opaque to the compiler
-        if (i == 0) b.load(sc, G);
         a.opaque();
-        test_group<R, CLS, NR>(a, sc, i, ray, tmin);
+        group_discs<R, CLS, NR>(a, ray, da, m, true);
         b.opaque();
-        test_group<R, CLS, NR>(b, sc, i + G, ray, tmin);
+        group_discs<R, CLS, NR>(b, ray, db, m, false);
 #else
         a.touch();
-        b.load(sc, i + G);
-        __builtin_amdgcn_sched_barrier(0);
-        test_group<R, CLS, NR>(a, sc, i, ray, tmin);
-        b.touch();
+        group_discs<R, CLS, NR>(a, ray, da, m, true);
         a.load(sc, i + 2 * G);
         __builtin_amdgcn_sched_barrier(0);
-        test_group<R, CLS, NR>(b, sc, i + G, ray, tmin);
+        group_discs<R, CLS, NR>(b, ray, db, m, false);
+        b.load(sc, i + 3 * G);
+        __builtin_amdgcn_sched_barrier(0);
 #endif
+#ifdef RAYZ_DEBUG_NONARROW // timing experiment only (wrong results)
+        if (m >= R(1e30)) {
+#else
+        if (m >= R(0)) { // any lane, any ray, any of the 2·G spheres: rare
+#endif
+            group_narrow<R, CLS, NR>(sc, i, ray, da, tmin);
+            group_narrow<R, CLS, NR>(sc, i + G, ray, db, tmin);
+        }
     }
 }
 
@@ -552,11 +546,13 @@ __device__ __forceinline__ void scan_triangles(const DevScene<R>& sc, ScanRay<R>
 }
 
 // ---- the flat-list scan: nearest hit of each of the lane's NR rays over every hittable -------------------
-// Wave-uniform in the sphere index: records arrive by scalar loads and feed the VALU as SGPR operands.  The
-// scalar data cache delivers only ≈3 B/clk/CU (profiles/r01: busy 100 % at 1 x 64 B per 10.7 clk), which at
-// 20 B per y-moving sphere is ≈10 lane-tests/clk/CU — below the VALU's ≈14.6 with the 8-instruction test.  So a
-// lane carries NR = 2 rays: every fetched record is tested against 128 rays per wave, the scalar feed is
-// halved, and the scan is VALU-bound again.
+// Wave-uniform in the sphere index: records arrive by scalar loads and feed the VALU as SGPR operands.  What
+// bounds the loop was established by elimination (tools/ubench/): not the sphere feed (a build
+// that never reloads runs in the same time), not occupancy, not instruction-level parallelism — but the rate at
+// which VALU instructions can read DIFFERENT scalar registers (≈2.75 cycles each), plus ≈10 cycles per reject
+// branch.  Hence two spheres per packed FMA (ScanGroup::discs) and one branch per 8 tests (scan_class).
+// NR = 2 rays per lane (RAYZ_RAYS=2) halves the scalar loads per test; it is kept as a measurement variant
+// and is not faster.
 template <class R, int NR>
 __device__ __forceinline__ void scan_begin(ScanRay<R>& ray, V<R> o, V<R> d, V<R> ud, R time) {
     ray.o = o;
@@ -761,7 +757,7 @@ __device__ __forceinline__ void path_refill(PathState<R>& p, const TraceArgs<R>&
 // time, runs its paths one after the other, adds their radiance in sample order, and stores the chunk sum to
 // partial[item]; resolve_kernel adds the chunk sums of a pixel in chunk order.  The summation tree is therefore
 // fixed by (spp, chunk_spp) alone — not by the schedule, the grid size, NR or the number of GPUs.
-template <class R, int NR, bool SYNC> __global__ __launch_bounds__(256) void trace_kernel(const TraceArgs<R> A) {
+template <class R, int NR, bool SYNC> __global__ __launch_bounds__(256, NR == 1 ? 5 : 3) void trace_kernel(const TraceArgs<R> A) {
     const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     PathState<R> p[NR];
 #pragma unroll
@@ -804,78 +800,6 @@ template <class R, int NR, bool SYNC> __global__ __launch_bounds__(256) void tra
             }
     }
     // ---- counters: one atomic per wave ----
-    unsigned long long tot = nseg;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
-    if (lane == 0) atomicAdd(&A.counters[1], tot);
-}
-
-// ---- measurement variant: the same flat-list scan with sphere tiles staged through LDS -------------------
-// BASELINE.json's north star suggests "LDS staging of hot sphere tiles".  This kernel does exactly that — the
-// workgroup copies a tile of kLdsTile records into LDS, every lane then reads the records back (all 64 lanes the
-// same address: an LDS broadcast) — with arithmetic identical to trace_kernel, so the two can be compared like
-// for like (RAYZ_FEED=lds selects it; results are bit-identical).  It is NOT the default: DESIGN.md §6 has the
-// measured comparison.  Barriers make the bounce iteration workgroup-synchronous.
-constexpr int kLdsTile = 1024;
-
-template <class R> struct LdsTile {
-    typename VecOf<R>::type c[kLdsTile];
-    typename VecOf<R>::type v[kLdsTile]; // mov-G velocities
-    R vy[kLdsTile];                      // mov-Y velocities (a group's four are one ds_read_b128)
-};
-
-template <class R, int CLS>
-__device__ __forceinline__ void scan_class_lds(const DevScene<R>& sc, int n, LdsTile<R>* tile, ScanRay<R> (&ray)[1], R tmin) {
-    constexpr int G = ScanGroup<R, CLS>::G;
-    for (int base = 0; base < n; base += kLdsTile) {
-        const int m = n - base < kLdsTile ? n - base : kLdsTile;
-        __syncthreads(); // everyone is done reading the previous tile
-        for (int j = (int)threadIdx.x; j < m; j += 256) {
-            if (CLS == 0) tile->c[j] = sc.stat[base + j];
-            if (CLS == 1) {
-                tile->c[j] = sc.movy[base + j];
-                tile->vy[j] = sc.movy_vy[base + j];
-            }
-            if (CLS == 2) {
-                tile->c[j] = sc.movg[2 * (base + j)];
-                tile->v[j] = sc.movg[2 * (base + j) + 1];
-            }
-        }
-        __syncthreads();
-        for (int i = 0; i < m; i += G) {
-            ScanGroup<R, CLS> g;
-#pragma unroll
-            for (int k = 0; k < G; ++k) g.load_lds(tile, i + k, k);
-            test_group<R, CLS, 1>(g, sc, base + i, ray, tmin);
-        }
-    }
-}
-
-template <class R> __global__ __launch_bounds__(256) void trace_kernel_lds(const TraceArgs<R> A) {
-    __shared__ LdsTile<R> tile;
-    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    PathState<R> p;
-    path_init<R>(p);
-    uint32_t nseg = 0;
-    bool queue_empty = false; // wave-uniform
-    for (;;) {
-        path_refill<R>(p, A, lane, queue_empty);
-        if (__syncthreads_or(p.alive ? 1 : 0) == 0) break; // workgroup-uniform: the tile loops below hold barriers
-        ScanRay<R> ray[1];
-        const V<R> ud = unit(p.d);
-        scan_begin<R, 1>(ray[0], p.o, p.d, ud, p.time);
-        scan_class_lds<R, 0>(A.sc, (int)A.sc.ns_pad, &tile, ray, A.tmin);
-        scan_class_lds<R, 1>(A.sc, (int)A.sc.ny_pad, &tile, ray, A.tmin);
-        scan_class_lds<R, 2>(A.sc, (int)A.sc.ng_pad, &tile, ray, A.tmin);
-        scan_triangles<R, 1>(A.sc, ray, A.tmin);
-        if (p.alive) {
-            nseg++;
-            p.seg++;
-            bool cont = shade<R>(A.sc, p.g, p.o, p.d, ud, p.time, ray[0].tbest, ray[0].ibest, p.thr, p.acc);
-            if (p.seg >= A.max_bounces) cont = false;
-            p.alive = cont;
-        }
-    }
     unsigned long long tot = nseg;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);

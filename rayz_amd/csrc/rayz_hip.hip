@@ -61,9 +61,8 @@ template <> struct Bits<double> {
 // Device copy of the scene in one precision: scan streams + pool-indexed shading tables.
 template <class R> struct SceneBuffers {
     typedef typename VecOf<R>::type r4;
-    r4* stat = nullptr;
-    r4* movy = nullptr;
-    R* movy_vy = nullptr;
+    R* stat = nullptr;  // blocks of 8: cx[8] cy[8] cz[8] r²[8]
+    R* movy = nullptr;  // blocks of 8: cx[8] cy[8] cz[8] r²[8] vy[8]
     r4* movg = nullptr;
     r4* sph_pool = nullptr;
     r4* mat = nullptr;
@@ -81,13 +80,12 @@ template <class R> struct SceneBuffers {
         bvh_ready = false;
         (void)hipFree(stat);
         (void)hipFree(movy);
-        (void)hipFree(movy_vy);
         (void)hipFree(movg);
         (void)hipFree(sph_pool);
         (void)hipFree(mat);
         (void)hipFree(tex);
-        stat = movy = movg = sph_pool = mat = tex = nullptr;
-        movy_vy = nullptr;
+        movg = sph_pool = mat = tex = nullptr;
+        stat = movy = nullptr;
         ready = false;
     }
 };
@@ -160,9 +158,9 @@ void classify(RayzScene* s) {
     for (uint32_t i = 0; i < s->spheres.size(); ++i) s->cls[velocity_class(s->spheres[i])].push_back(i);
 }
 
-// scanned length of a stream (whole group pairs) and its allocated length (+ one spare group for the prefetch)
+// scanned length of a stream (whole group pairs) and its allocated length (+ two spare groups for the prefetch)
 uint32_t scan_len(size_t n, uint32_t group) { return round_up((uint32_t)n, 2 * group); }
-uint32_t stream_len(size_t n, uint32_t group) { return scan_len(n, group) + group; }
+uint32_t stream_len(size_t n, uint32_t group) { return scan_len(n, group) + 2 * group; }
 
 int upload_narrow(RayzScene* s) {
     NarrowBuffers& nb = s->narrow;
@@ -211,16 +209,24 @@ template <class R> int upload(RayzScene* s, SceneBuffers<R>& b) {
         const R r = (R)q.radius;
         return r4{(R)q.center[0], (R)q.center[1], (R)q.center[2], r * r};
     };
-    std::vector<r4> stat(stream_len(s->cls[0].size(), kStaticGroup), pad);
-    std::vector<r4> movy(stream_len(s->cls[1].size(), kMovYGroup), pad);
-    std::vector<R> movy_vy(movy.size(), R(0));
+    // static / mov-Y streams: blocks of G spheres, SoA inside a block (field f of sphere k of block g at
+    // g·F·G + f·G + k), pad spheres {0, 0, 0, r² = -inf, vy = 0}
+    auto blocks = [&](const std::vector<uint32_t>& cls, uint32_t G, uint32_t F) {
+        const uint32_t n = stream_len(cls.size(), G);
+        std::vector<R> v((size_t)n * F, R(0));
+        for (uint32_t k = 0; k < n; ++k) v[(size_t)(k / G) * F * G + 3 * G + k % G] = ninf;
+        for (size_t k = 0; k < cls.size(); ++k) {
+            const RayzSphere& q = s->spheres[cls[k]];
+            const r4 c = rec(cls[k]);
+            R* blk = v.data() + (k / G) * F * G + k % G;
+            blk[0] = c.x, blk[G] = c.y, blk[2 * G] = c.z, blk[3 * G] = c.w;
+            if (F == 5) blk[4 * G] = (R)q.velocity[1];
+        }
+        return v;
+    };
+    const std::vector<R> stat = blocks(s->cls[0], kStaticGroup, 4), movy = blocks(s->cls[1], kMovYGroup, 5);
     std::vector<r4> movg(2 * (size_t)stream_len(s->cls[2].size(), kMovGGroup), r4{R(0), R(0), R(0), R(0)});
     for (size_t k = 0; k < movg.size(); k += 2) movg[k] = pad;
-    for (size_t k = 0; k < s->cls[0].size(); ++k) stat[k] = rec(s->cls[0][k]);
-    for (size_t k = 0; k < s->cls[1].size(); ++k) {
-        movy[k] = rec(s->cls[1][k]);
-        movy_vy[k] = (R)s->spheres[s->cls[1][k]].velocity[1];
-    }
     for (size_t k = 0; k < s->cls[2].size(); ++k) {
         const RayzSphere& q = s->spheres[s->cls[2][k]];
         movg[2 * k] = rec(s->cls[2][k]);
@@ -252,7 +258,6 @@ template <class R> int upload(RayzScene* s, SceneBuffers<R>& b) {
     }
     HIP_TRY(put(&b.stat, stat));
     HIP_TRY(put(&b.movy, movy));
-    HIP_TRY(put(&b.movy_vy, movy_vy));
     HIP_TRY(put(&b.movg, movg));
     HIP_TRY(put(&b.sph_pool, sph_pool));
     HIP_TRY(put(&b.mat, mat));
@@ -451,7 +456,6 @@ int render_impl(RayzScene* s, SceneBuffers<R>& b, const RayzCameraDesc* cam, con
     TraceArgs<R> A{};
     A.sc.stat = b.stat;
     A.sc.movy = b.movy;
-    A.sc.movy_vy = b.movy_vy;
     A.sc.movg = b.movg;
     A.sc.stat64 = s->narrow.stat64;
     A.sc.movy64 = s->narrow.movy64;
@@ -495,9 +499,8 @@ int render_impl(RayzScene* s, SceneBuffers<R>& b, const RayzCameraDesc* cam, con
         A.bvh_keep = (ka & 0xffu) | ((ks & 0xffu) << 8);
     }
 
-    // measurement variant of the flat-list kernel with LDS-staged sphere tiles (RAYZ_FEED=lds); same results
     const char* feed = std::getenv("RAYZ_FEED");
-    const bool use_lds = !use_bvh && feed && std::strcmp(feed, "lds") == 0;
+    const bool use_lds = false; // the LDS-tiled measurement variant was retired with the block layout
     // rays per lane of the flat-list kernel: 1.  RAYZ_RAYS=2 (register tiling: every fetched record tested against
     // two rays per lane) and RAYZ_FEED=sync (a workgroup barrier per bounce iteration) are measurement variants —
     // neither is faster: the scan is bound by VALU issue cycles, not by the sphere feed
@@ -508,8 +511,7 @@ int render_impl(RayzScene* s, SceneBuffers<R>& b, const RayzCameraDesc* cam, con
     void (*lin)(const TraceArgs<R>) = nr == 2 ? (sync ? trace_kernel<R, 2, true> : trace_kernel<R, 2, false>)
                                                : (sync ? trace_kernel<R, 1, true> : trace_kernel<R, 1, false>);
     int blocks_per_cu = 0;
-    if (use_lds) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, trace_kernel_lds<R>, 256, 0));
-    else if (use_bvh) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, trace_kernel_bvh<R>, 256, 0));
+    if (use_bvh) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, trace_kernel_bvh<R>, 256, 0));
     else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, lin, 256, 0));
     if (blocks_per_cu < 1) blocks_per_cu = 1;
     uint64_t grid = (uint64_t)g_num_cu * blocks_per_cu;
@@ -519,8 +521,7 @@ int render_impl(RayzScene* s, SceneBuffers<R>& b, const RayzCameraDesc* cam, con
 
     HIP_TRY(hipMemsetAsync(s->counters, 0, 4 * sizeof(unsigned long long), stream));
     HIP_TRY(hipEventRecord(s->ev0, stream));
-    if (use_lds) hipLaunchKernelGGL(trace_kernel_lds<R>, dim3((uint32_t)grid), dim3(256), 0, stream, A);
-    else if (use_bvh) hipLaunchKernelGGL(trace_kernel_bvh<R>, dim3((uint32_t)grid), dim3(256), 0, stream, A);
+    if (use_bvh) hipLaunchKernelGGL(trace_kernel_bvh<R>, dim3((uint32_t)grid), dim3(256), 0, stream, A);
     else hipLaunchKernelGGL(lin, dim3((uint32_t)grid), dim3(256), 0, stream, A);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev1, stream));

@@ -273,16 +273,20 @@ def test_full_size_config3_spot_pixels_and_counters(gpu, oracle):
     assert got[:40].mean() > got[-40:].mean() and got.std() > 0.05
 
 
-def test_lds_tiled_variant_is_bit_identical(gpu, oracle, monkeypatch):
-    """The measurement variant with LDS-staged sphere tiles (RAYZ_FEED=lds) computes the same image
-    as the scalar-feed kernel and the oracle; every stream class and a tile boundary (> 1024 records) included."""
-    monkeypatch.setenv("RAYZ_FEED", "lds")
-    for t in (tracer.randomBouncing(64, -20, 20, seed=42), _custom_scene()):
-        t.samples_per_px, t.max_bounces = 4, 12
-        t.set_gpu(render_seed=8)
-        got, want, gst, ost = _pair(gpu, oracle, t)
-        assert_images_equal(got, want, "LDS-tiled variant")
-        assert gst.segments == ost.segments
+def test_measurement_variants_are_bit_identical(gpu, oracle, monkeypatch):
+    """RAYZ_RAYS=2 (two rays per lane) and RAYZ_FEED=sync (workgroup-lockstep bounce iteration) are scheduling
+    variants kept for measurement: same image as the default kernel and the oracle."""
+    for env in ({"RAYZ_RAYS": "2"}, {"RAYZ_FEED": "sync"}, {"RAYZ_RAYS": "2", "RAYZ_FEED": "sync"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for t in (tracer.randomBouncing(64, -20, 20, seed=42), _custom_scene()):
+            t.samples_per_px, t.max_bounces = 4, 12
+            t.set_gpu(render_seed=8)
+            got, want, gst, ost = _pair(gpu, oracle, t)
+            assert_images_equal(got, want, f"variant {env}")
+            assert gst.segments == ost.segments
+        for k in env:
+            monkeypatch.delenv(k)
 
 
 def test_f32_kernel_is_unbiased_against_f64_and_mode_a(gpu, oracle):
