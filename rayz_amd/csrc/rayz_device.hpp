@@ -57,9 +57,7 @@ template <class R> struct DevScene {
     const R* stat;           // [4 * ns_pad + spare block]
     const R* movy;           // [5 * ny_pad + spare block]
     const r4* movg;
-    const d4* stat64;        // [ns_pad]      {cx, cy, cz, r²}          (aliases stat for R = double)
-    const d4* movy64;        // [2 * ny_pad]  {cx, cy, cz, r²}, {0, vy, 0, 0}
-    const d4* movg64;        // [2 * ng_pad]  (aliases movg for R = double)
+    const d4* slot64;        // [2 * slots] the pool's own f64 values per slot: {cx, cy, cz, r²}, {vx, vy, vz, 0}
     const uint32_t* slot_pool; // [slots] pool index of each slot
     const r4* sph_pool;      // [2 * n_spheres] by POOL index: {cx, cy, cz, r²}, {vx, vy, vz, bits(material)}
     const r4* mat;           // [n_mat] {bits(kind | method << 8), bits(texture), param, 1/param}
@@ -191,34 +189,26 @@ __device__ __forceinline__ V<R> texture_value(const DevScene<R>& sc, uint32_t id
 // ---- narrow phase: one candidate that passed the reject test, src/geom.zig:40-61 ------------------
 // The reference's quadratic in f64 on the pool's f64 sphere, for the ray as the kernel holds it; the
 // chosen root is rounded to R.  Ties in t go to the larger pool index (the reference's "t ≤ maxt, later
-// wins" over its flat list, src/hit.zig:208-214), which makes the result independent of the scan order.
-// `rec` and `pool` are wave-uniform (scalar loads).
-template <class R, bool MOVING>
-__device__ __forceinline__ void narrow_phase(const RAYZ_CONSTANT d4* rec, int pool, R disc_fast, V<R> o, V<R> d, R time,
-                                             double inv_a2, R tmin, R& tbest, int& ibest) {
-    if (disc_fast >= R(0)) {
-        const d4 c = rec[0];
-        const double dx = d.x, dy = d.y, dz = d.z;
-        double qx = c.x - (double)o.x, qy = c.y - (double)o.y, qz = c.z - (double)o.z;
-        if (MOVING) {
-            const d4 v = rec[1];
-            const double tm = time;
-            qx = fm(v.x, tm, qx);
-            qy = fm(v.y, tm, qy);
-            qz = fm(v.z, tm, qz);
-        }
-        const double a2 = fm(dz, dz, fm(dy, dy, dx * dx));
-        const double hb2 = fm(dz, qz, fm(dy, qy, dx * qx));
-        const double cc2 = fm(qz, qz, fm(qy, qy, fm(qx, qx, -c.w)));
-        const double disc2 = fm(-a2, cc2, hb2 * hb2);
-        if (disc2 >= 0.0) {
-            const double rt = __builtin_sqrt(disc2);
-            const R t1 = (R)((hb2 - rt) * inv_a2), t2 = (R)((hb2 + rt) * inv_a2);
-            const R t = t1 >= tmin ? t1 : t2;
-            if (t >= tmin && (t < tbest || (t == tbest && pool > ibest))) {
-                tbest = t;
-                ibest = pool;
-            }
+// wins" over its flat list, src/hit.zig:208-214), which makes the result independent of the order in which
+// candidates are examined — so the flat-list scan only PARKS candidate slots (≤ 4 per ray) and evaluates
+// them afterwards for all lanes together, instead of interrupting the scan ~30 times per segment for one or two
+// lanes each.
+template <class R>
+__device__ __forceinline__ void narrow_eval(const d4 c, const d4 v, int pool, V<R> o, V<R> d, R time, double inv_a2, R tmin,
+                                            R& tbest, int& ibest) {
+    const double dx = d.x, dy = d.y, dz = d.z, tm = time;
+    const double qx = fm(v.x, tm, c.x - (double)o.x), qy = fm(v.y, tm, c.y - (double)o.y), qz = fm(v.z, tm, c.z - (double)o.z);
+    const double a2 = fm(dz, dz, fm(dy, dy, dx * dx));
+    const double hb2 = fm(dz, qz, fm(dy, qy, dx * qx));
+    const double cc2 = fm(qz, qz, fm(qy, qy, fm(qx, qx, -c.w)));
+    const double disc2 = fm(-a2, cc2, hb2 * hb2);
+    if (disc2 >= 0.0) {
+        const double rt = __builtin_sqrt(disc2);
+        const R t1 = (R)((hb2 - rt) * inv_a2), t2 = (R)((hb2 + rt) * inv_a2);
+        const R t = t1 >= tmin ? t1 : t2;
+        if (t >= tmin && (t < tbest || (t == tbest && pool > ibest))) {
+            tbest = t;
+            ibest = pool;
         }
     }
 }
@@ -341,11 +331,7 @@ template <class R> struct ScanGroup<R, 0> { // static
             out[2 * q + 1] = d.y;
         }
     }
-    static __device__ __forceinline__ const RAYZ_CONSTANT d4* rec64(const DevScene<R>& sc, int i) {
-        return (const RAYZ_CONSTANT d4*)sc.stat64 + i;
-    }
     static __device__ __forceinline__ int slot0(const DevScene<R>&) { return 0; }
-    static constexpr bool kMoving = false;
 };
 template <class R> struct ScanGroup<R, 1> { // mov-Y
     typedef typename VecOf<R>::pair pr;
@@ -379,11 +365,7 @@ template <class R> struct ScanGroup<R, 1> { // mov-Y
             out[2 * q + 1] = d.y;
         }
     }
-    static __device__ __forceinline__ const RAYZ_CONSTANT d4* rec64(const DevScene<R>& sc, int i) {
-        return (const RAYZ_CONSTANT d4*)sc.movy64 + 2 * i;
-    }
     static __device__ __forceinline__ int slot0(const DevScene<R>& sc) { return (int)sc.ns_pad; }
-    static constexpr bool kMoving = true;
 };
 template <class R> struct ScanGroup<R, 2> { // mov-G
     typedef typename VecOf<R>::type r4;
@@ -410,11 +392,7 @@ template <class R> struct ScanGroup<R, 2> { // mov-G
 #pragma unroll
         for (int k = 0; k < G; ++k) out[k] = disc(k, b, time);
     }
-    static __device__ __forceinline__ const RAYZ_CONSTANT d4* rec64(const DevScene<R>& sc, int i) {
-        return (const RAYZ_CONSTANT d4*)sc.movg64 + 2 * i;
-    }
     static __device__ __forceinline__ int slot0(const DevScene<R>& sc) { return (int)(sc.ns_pad + sc.ny_pad); }
-    static constexpr bool kMoving = true;
 };
 
 // What the scan needs of one ray (one of the NR rays a lane carries).
@@ -425,6 +403,8 @@ template <class R> struct ScanRay {
     double inv_a2; // 1 / (d·d) in f64, for the narrow phase
     R tbest;
     int ibest;
+    uint32_t cand[4]; // parked candidate slots (spheres whose line-distance test passed), evaluated by narrow_flush
+    uint32_t ncand;
 };
 
 // Reject tests of one group for the lane's NR rays; the running maximum feeds the pair's single branch.
@@ -439,19 +419,42 @@ __device__ __forceinline__ void group_discs(const ScanGroup<R, CLS>& g, ScanRay<
         for (int k = 0; k < G; ++k) m = (first && r == 0 && k == 0) ? disc[0][0] : mx(m, disc[r][k]);
     }
 }
-// Narrow phase of one group's candidates (slots i .. i+G-1).
+// Evaluate every parked candidate of the wave's lanes (round j: lanes with more than j parked slots).
+template <class R, int NR> __device__ __forceinline__ void narrow_flush(const DevScene<R>& sc, ScanRay<R> (&ray)[NR], R tmin) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (__ballot(ray[r].ncand > (uint32_t)j) == 0ull) break;
+            if (ray[r].ncand > (uint32_t)j) {
+                const uint32_t slot = ray[r].cand[j];
+                narrow_eval<R>(sc.slot64[2 * slot], sc.slot64[2 * slot + 1], (int)sc.slot_pool[slot], ray[r].o, ray[r].d,
+                               ray[r].time, ray[r].inv_a2, tmin, ray[r].tbest, ray[r].ibest);
+            }
+        }
+        ray[r].ncand = 0;
+    }
+}
+// Park one group's candidates (slots first .. first+G-1); a lane whose list is full forces a flush first.
 template <class R, int CLS, int NR>
-__device__ __forceinline__ void group_narrow(const DevScene<R>& sc, int i, ScanRay<R> (&ray)[NR],
-                                             const R (&disc)[NR][ScanGroup<R, CLS>::G], R tmin) {
+__device__ __forceinline__ void group_collect(const DevScene<R>& sc, int first, ScanRay<R> (&ray)[NR],
+                                              const R (&disc)[NR][ScanGroup<R, CLS>::G], R tmin) {
     constexpr int G = ScanGroup<R, CLS>::G;
-    const RAYZ_CONSTANT uint32_t* slot_pool = (const RAYZ_CONSTANT uint32_t*)sc.slot_pool + ScanGroup<R, CLS>::slot0(sc);
 #pragma unroll
     for (int k = 0; k < G; ++k)
 #pragma unroll
-        for (int r = 0; r < NR; ++r)
-            narrow_phase<R, ScanGroup<R, CLS>::kMoving>(ScanGroup<R, CLS>::rec64(sc, i + k), (int)slot_pool[i + k], disc[r][k],
-                                                        ray[r].o, ray[r].d, ray[r].time, ray[r].inv_a2, tmin, ray[r].tbest,
-                                                        ray[r].ibest);
+        for (int r = 0; r < NR; ++r) {
+            const bool want = disc[r][k] >= R(0);
+            if (__ballot(want && ray[r].ncand == 4u) != 0ull) narrow_flush<R, NR>(sc, ray, tmin);
+            if (want) {
+                const uint32_t slot = (uint32_t)(first + k), n = ray[r].ncand;
+                ray[r].cand[0] = n == 0u ? slot : ray[r].cand[0];
+                ray[r].cand[1] = n == 1u ? slot : ray[r].cand[1];
+                ray[r].cand[2] = n == 2u ? slot : ray[r].cand[2];
+                ray[r].cand[3] = n == 3u ? slot : ray[r].cand[3];
+                ray[r].ncand = n + 1u;
+            }
+        }
 }
 
 // One velocity class.  n is a multiple of 2·G and the stream carries two spare groups.  Per iteration: wait for
@@ -488,8 +491,9 @@ __device__ __forceinline__ void scan_class(const DevScene<R>& sc, int n, ScanRay
 #else
         if (m >= R(0)) { // any lane, any ray, any of the 2·G spheres: rare
 #endif
-            group_narrow<R, CLS, NR>(sc, i, ray, da, tmin);
-            group_narrow<R, CLS, NR>(sc, i + G, ray, db, tmin);
+            const int slot0 = ScanGroup<R, CLS>::slot0(sc);
+            group_collect<R, CLS, NR>(sc, slot0 + i, ray, da, tmin);
+            group_collect<R, CLS, NR>(sc, slot0 + i + G, ray, db, tmin);
         }
     }
 }
@@ -563,11 +567,14 @@ __device__ __forceinline__ void scan_begin(ScanRay<R>& ray, V<R> o, V<R> d, V<R>
     ray.inv_a2 = 1.0 / fm(ddz, ddz, fm(ddy, ddy, ddx * ddx));
     ray.tbest = (R)__builtin_inff();
     ray.ibest = -1;
+    ray.cand[0] = ray.cand[1] = ray.cand[2] = ray.cand[3] = 0u;
+    ray.ncand = 0u;
 }
 template <class R, int NR> __device__ __forceinline__ void scan_spheres(const DevScene<R>& sc, ScanRay<R> (&ray)[NR], R tmin) {
     scan_class<R, 0, NR>(sc, (int)sc.ns_pad, ray, tmin);
     scan_class<R, 1, NR>(sc, (int)sc.ny_pad, ray, tmin);
     scan_class<R, 2, NR>(sc, (int)sc.ng_pad, ray, tmin);
+    narrow_flush<R, NR>(sc, ray, tmin);
     scan_triangles<R, NR>(sc, ray, tmin);
 }
 

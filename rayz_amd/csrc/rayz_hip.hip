@@ -92,9 +92,7 @@ template <class R> struct SceneBuffers {
 
 // The pool's own f64 records in slot order (narrow phase) + slot → pool index; shared by both precisions.
 struct NarrowBuffers {
-    d4* stat64 = nullptr;
-    d4* movy64 = nullptr;
-    d4* movg64 = nullptr;
+    d4* slot64 = nullptr;
     uint32_t* slot_pool = nullptr;
     d4* bvh_sph64 = nullptr; // leaf order (BVH traversal only)
     uint32_t ns_pad = 0, ny_pad = 0, ng_pad = 0;
@@ -103,11 +101,9 @@ struct NarrowBuffers {
         (void)hipFree(bvh_sph64);
         bvh_sph64 = nullptr;
         bvh_ready = false;
-        (void)hipFree(stat64);
-        (void)hipFree(movy64);
-        (void)hipFree(movg64);
+        (void)hipFree(slot64);
         (void)hipFree(slot_pool);
-        stat64 = movy64 = movg64 = nullptr;
+        slot64 = nullptr;
         slot_pool = nullptr;
         ready = false;
     }
@@ -169,29 +165,19 @@ int upload_narrow(RayzScene* s) {
     nb.ns_pad = scan_len(s->cls[0].size(), kStaticGroup);
     nb.ny_pad = scan_len(s->cls[1].size(), kMovYGroup);
     nb.ng_pad = scan_len(s->cls[2].size(), kMovGGroup);
-    const double ninf = -std::numeric_limits<double>::infinity();
-    std::vector<d4> stat64(nb.ns_pad, d4{0, 0, 0, ninf}), movy64(2 * (size_t)nb.ny_pad, d4{0, 0, 0, 0}),
-        movg64(2 * (size_t)nb.ng_pad, d4{0, 0, 0, 0});
-    std::vector<uint32_t> slot_pool((size_t)nb.ns_pad + nb.ny_pad + nb.ng_pad, 0u);
-    for (uint32_t k = 0; k < nb.ny_pad; ++k) movy64[2 * k].w = ninf;
-    for (uint32_t k = 0; k < nb.ng_pad; ++k) movg64[2 * k].w = ninf;
-    auto rec = [&](uint32_t pool) {
+    const size_t slots = (size_t)nb.ns_pad + nb.ny_pad + nb.ng_pad;
+    std::vector<d4> slot64(2 * slots, d4{0, 0, 0, 0});
+    std::vector<uint32_t> slot_pool(slots, 0u);
+    auto place = [&](size_t slot, uint32_t pool) {
         const RayzSphere& q = s->spheres[pool];
-        return d4{q.center[0], q.center[1], q.center[2], q.radius * q.radius}; // radius * radius in f64, src/geom.zig:45
+        slot64[2 * slot] = d4{q.center[0], q.center[1], q.center[2], q.radius * q.radius}; // radius * radius in f64, src/geom.zig:45
+        slot64[2 * slot + 1] = d4{q.velocity[0], q.velocity[1], q.velocity[2], 0.0};
+        slot_pool[slot] = pool;
     };
-    auto vel = [&](uint32_t pool) {
-        const RayzSphere& q = s->spheres[pool];
-        return d4{q.velocity[0], q.velocity[1], q.velocity[2], 0.0};
-    };
-    for (size_t k = 0; k < s->cls[0].size(); ++k) stat64[k] = rec(s->cls[0][k]), slot_pool[k] = s->cls[0][k];
-    for (size_t k = 0; k < s->cls[1].size(); ++k)
-        movy64[2 * k] = rec(s->cls[1][k]), movy64[2 * k + 1] = vel(s->cls[1][k]), slot_pool[nb.ns_pad + k] = s->cls[1][k];
-    for (size_t k = 0; k < s->cls[2].size(); ++k)
-        movg64[2 * k] = rec(s->cls[2][k]), movg64[2 * k + 1] = vel(s->cls[2][k]),
-        slot_pool[nb.ns_pad + nb.ny_pad + k] = s->cls[2][k];
-    HIP_TRY(put(&nb.stat64, stat64));
-    HIP_TRY(put(&nb.movy64, movy64));
-    HIP_TRY(put(&nb.movg64, movg64));
+    for (size_t k = 0; k < s->cls[0].size(); ++k) place(k, s->cls[0][k]);
+    for (size_t k = 0; k < s->cls[1].size(); ++k) place(nb.ns_pad + k, s->cls[1][k]);
+    for (size_t k = 0; k < s->cls[2].size(); ++k) place((size_t)nb.ns_pad + nb.ny_pad + k, s->cls[2][k]);
+    HIP_TRY(put(&nb.slot64, slot64));
     HIP_TRY(put(&nb.slot_pool, slot_pool));
     nb.ready = true;
     return RAYZ_OK;
@@ -457,9 +443,7 @@ int render_impl(RayzScene* s, SceneBuffers<R>& b, const RayzCameraDesc* cam, con
     A.sc.stat = b.stat;
     A.sc.movy = b.movy;
     A.sc.movg = b.movg;
-    A.sc.stat64 = s->narrow.stat64;
-    A.sc.movy64 = s->narrow.movy64;
-    A.sc.movg64 = s->narrow.movg64;
+    A.sc.slot64 = s->narrow.slot64;
     A.sc.slot_pool = s->narrow.slot_pool;
     A.sc.sph_pool = b.sph_pool;
     A.sc.mat = b.mat;
