@@ -764,7 +764,7 @@ __device__ __forceinline__ void path_refill(PathState<R>& p, const TraceArgs<R>&
 // time, runs its paths one after the other, adds their radiance in sample order, and stores the chunk sum to
 // partial[item]; resolve_kernel adds the chunk sums of a pixel in chunk order.  The summation tree is therefore
 // fixed by (spp, chunk_spp) alone — not by the schedule, the grid size, NR or the number of GPUs.
-template <class R, int NR, bool SYNC> __global__ __launch_bounds__(256, NR == 1 ? 5 : 3) void trace_kernel(const TraceArgs<R> A) {
+template <class R, int NR, bool SYNC> __global__ __launch_bounds__(256, NR == 1 ? 4 : 3) void trace_kernel(const TraceArgs<R> A) {
     const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     PathState<R> p[NR];
 #pragma unroll
