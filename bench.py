@@ -194,10 +194,11 @@ def main():
             executed_flops = frame_segments / world * (n_static * EXEC_FLOP_STATIC + n_movy * EXEC_FLOP_MOVY +
                                                        (n_moving - n_movy) * EXEC_FLOP_MOVG)
             kernel = "trace_kernel<%s>" % ("double" if args.precision == "f64" else "float")
-            note = ("VALU-bound, not HBM/MFMA (SURVEY.md 8d). achieved/frac use SURVEY 8d's algorithmic flops of the "
-                    "reference's quadratic: segments x (18 x static + 24 x moving spheres); `executed` counts what the "
-                    "kernel's cheaper reject test really issues (14 / 16 / 24 flop per static / y-moving / moving sphere). "
-                    "The scene (320 KB) is L2/scalar-cache resident")
+            note = ("VALU-bound, not HBM/MFMA (SURVEY.md 8d): the scene (320 KB) is L2 / scalar-cache resident. achieved/frac "
+                    "count the flops of the kernel's own reject test (7 / 8 / 12 FMA = 14 / 16 / 24 flop per static / "
+                    "y-moving / moving sphere, DESIGN.md 4.3) x segments; `reference_formulation` prices the same frame "
+                    "with SURVEY 8d's figure for the reference's quadratic (18 / 24 flop per test), which this kernel "
+                    "does not execute - that fraction can exceed 1")
         else:
             st_last = dscene.sync()
             # slab test: 6 sub + 6 mul + 6 min/max + 2 three-way min/max + slack mul = 21 flop; leaf sphere test 24
@@ -206,17 +207,18 @@ def main():
             kernel = "trace_kernel_bvh<%s>" % ("double" if args.precision == "f64" else "float")
             note = ("per-lane tree walk: divergence- and latency-bound, priced against the same FP32 vector peak; "
                     "algorithmic flops = 21 x box tests + 24 x leaf sphere tests")
-        achieved = flops / (kernel_ms_avg * 1e-3) / 1e12
         peak = PEAK_VALU_F32_TFLOPS / (2.0 if args.precision == "f64" else 1.0)
+        reference_achieved = flops / (kernel_ms_avg * 1e-3) / 1e12   # SURVEY 8d accounting
+        achieved = executed_flops / (kernel_ms_avg * 1e-3) / 1e12    # what the kernel executes
         # HBM bytes per launch from the committed PMC passes of this very command (profiles/), when they exist:
         # FETCH_SIZE doubled (gfx950 wide-read correction, MI355X_MICROARCH.md) + WRITE_SIZE, KiB -> bytes
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01", "r01_pmc_summary.json")
+        pmc = os.path.join(ROOT, "profiles", "r01", "pmc_summary.json")
         if (os.path.exists(pmc) and world == 1 and args.traversal == "linear" and args.precision == "f32"
                 and (args.width, args.spp, args.grid) == (1920, 1024, 50)):
             try:
                 z = json.load(open(pmc))
-                traffic = (2 * z["r01_pmc_fetch"]["FETCH_SIZE"] + z["r01_pmc_write"]["WRITE_SIZE"]) * 1024
+                traffic = (2 * z["r01b_pmc_fetch"]["FETCH_SIZE"] + z["r01b_pmc_write"]["WRITE_SIZE"]) * 1024
             except Exception:
                 traffic = None
         out = {
@@ -239,8 +241,8 @@ def main():
                 "bound": "valu_fp32" if args.precision == "f32" else "valu_fp64", "achieved": achieved, "peak": peak,
                 "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                 "kernel": kernel, "kernel_ms": kernel_ms_avg, "note": note,
-                "executed": {"achieved": executed_flops / (kernel_ms_avg * 1e-3) / 1e12,
-                             "frac": executed_flops / (kernel_ms_avg * 1e-3) / 1e12 / peak, "unit": "TFLOP/s"},
+                "reference_formulation": {"achieved": reference_achieved, "frac": reference_achieved / peak,
+                                          "unit": "TFLOP/s"},
                 "hbm": {"algorithmic_bytes": hbm_bytes, "achieved": hbm_bytes / (kernel_ms_avg * 1e-3) / 1e9,
                         "measured_bytes": traffic,
                         "measured": None if traffic is None else traffic / (kernel_ms_avg * 1e-3) / 1e9,
