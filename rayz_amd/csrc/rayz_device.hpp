@@ -34,8 +34,11 @@ constexpr int kMaxTextureDepth = 8;
 #ifndef RAYZ_GROUP
 #define RAYZ_GROUP 4
 #endif
-constexpr int kStaticGroup = RAYZ_GROUP; // spheres per scan group, by velocity class.  A stream is padded to a whole
-constexpr int kMovYGroup = RAYZ_GROUP;   //   number of group PAIRS plus one spare group, so that the prefetch of the
+// spheres per scan group (and per SoA block of a stream): 4 for f32, 2 for f64 — the two ping-pong SGPR sets of a
+// y-moving group are 2 x 5 x G registers of R, and more than ~40 SGPRs spill inside the loop
+template <class R> constexpr int group_size() { return sizeof(R) == 8 ? RAYZ_GROUP / 2 : RAYZ_GROUP; }
+constexpr int kStaticGroup = RAYZ_GROUP; // (f32 values; use group_size<R>())  A stream is padded to a whole
+constexpr int kMovYGroup = RAYZ_GROUP;   //   number of group PAIRS plus two spare groups, so that the prefetch of the
 constexpr int kMovGGroup = 2;   //   next group never leaves the array.
 constexpr int kTriGroup = 2;
 
@@ -304,7 +307,7 @@ template <class R, int CLS> struct ScanGroup;
 // bit-identical to the scalar form (and to the oracle).
 template <class R> struct ScanGroup<R, 0> { // static
     typedef typename VecOf<R>::pair pr;
-    static constexpr int G = kStaticGroup, H = kStaticGroup / 2;
+    static constexpr int G = group_size<R>(), H = G / 2;
     pr cx[H], cy[H], cz[H], r2[H];
     __device__ __forceinline__ void load(const DevScene<R>& sc, int i) {
         const RAYZ_CONSTANT pr* p = (const RAYZ_CONSTANT pr*)((const RAYZ_CONSTANT R*)sc.stat + 4 * i);
@@ -335,7 +338,7 @@ template <class R> struct ScanGroup<R, 0> { // static
 };
 template <class R> struct ScanGroup<R, 1> { // mov-Y
     typedef typename VecOf<R>::pair pr;
-    static constexpr int G = kMovYGroup, H = kMovYGroup / 2;
+    static constexpr int G = group_size<R>(), H = G / 2;
     pr cx[H], cy[H], cz[H], r2[H], vy[H];
     __device__ __forceinline__ void load(const DevScene<R>& sc, int i) {
         const RAYZ_CONSTANT pr* p = (const RAYZ_CONSTANT pr*)((const RAYZ_CONSTANT R*)sc.movy + 5 * i);

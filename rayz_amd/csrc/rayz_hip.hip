@@ -162,6 +162,7 @@ int upload_narrow(RayzScene* s) {
     NarrowBuffers& nb = s->narrow;
     if (nb.ready) return RAYZ_OK;
     classify(s);
+    // slot numbering is shared by both precisions: pad to the larger (f32) group size
     nb.ns_pad = scan_len(s->cls[0].size(), kStaticGroup);
     nb.ny_pad = scan_len(s->cls[1].size(), kMovYGroup);
     nb.ng_pad = scan_len(s->cls[2].size(), kMovGGroup);
@@ -197,8 +198,8 @@ template <class R> int upload(RayzScene* s, SceneBuffers<R>& b) {
     };
     // static / mov-Y streams: blocks of G spheres, SoA inside a block (field f of sphere k of block g at
     // g·F·G + f·G + k), pad spheres {0, 0, 0, r² = -inf, vy = 0}
-    auto blocks = [&](const std::vector<uint32_t>& cls, uint32_t G, uint32_t F) {
-        const uint32_t n = stream_len(cls.size(), G);
+    auto blocks = [&](const std::vector<uint32_t>& cls, uint32_t G, uint32_t F, uint32_t scanned) {
+        const uint32_t n = scanned + 2 * G; // the scanned slots (shared by both precisions) + two spare groups
         std::vector<R> v((size_t)n * F, R(0));
         for (uint32_t k = 0; k < n; ++k) v[(size_t)(k / G) * F * G + 3 * G + k % G] = ninf;
         for (size_t k = 0; k < cls.size(); ++k) {
@@ -210,7 +211,8 @@ template <class R> int upload(RayzScene* s, SceneBuffers<R>& b) {
         }
         return v;
     };
-    const std::vector<R> stat = blocks(s->cls[0], kStaticGroup, 4), movy = blocks(s->cls[1], kMovYGroup, 5);
+    const std::vector<R> stat = blocks(s->cls[0], group_size<R>(), 4, s->narrow.ns_pad),
+                         movy = blocks(s->cls[1], group_size<R>(), 5, s->narrow.ny_pad);
     std::vector<r4> movg(2 * (size_t)stream_len(s->cls[2].size(), kMovGGroup), r4{R(0), R(0), R(0), R(0)});
     for (size_t k = 0; k < movg.size(); k += 2) movg[k] = pad;
     for (size_t k = 0; k < s->cls[2].size(); ++k) {
