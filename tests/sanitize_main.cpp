@@ -1,0 +1,65 @@
+// sanitize_main.cpp — CPU-only AddressSanitizer / UBSan run over the host-side C++ of the repository:
+// the oracle (modes A and B, flat list and BVH, spheres and triangles), the host mirror (scene generators,
+// flatten, PPM writer) and the product's BVH builder.  Built and run by tests/test_sanitizers.py.
+#include "../oracle/rayz_oracle.cpp"
+#include "../rayz_amd/csrc/bvh_build.hpp"
+#include "../rayz_amd/host/rayz.hpp"
+
+#include <cstdio>
+
+// The host mirror's render() calls the HIP library; this CPU build has none.
+extern "C" int rayz_hip_render(const RayzSceneDesc*, const RayzCameraDesc*, const RayzRenderParams*, float*, RayzRenderStats*) { return RAYZ_ERR_NO_DEVICE; }
+extern "C" int rayz_hip_render_f64(const RayzSceneDesc*, const RayzCameraDesc*, const RayzRenderParams*, double*, RayzRenderStats*) { return RAYZ_ERR_NO_DEVICE; }
+extern "C" const char* rayz_hip_last_error(void) { return "no device in the sanitizer build"; }
+
+static int run(rayz::Tracer& t, const char* name) {
+    t.samples_per_px = 3;
+    t.max_bounces = 6;
+    const rayz::Tracer::Flat f = t.flatten();
+    const RayzSceneDesc sd = f.desc();
+    const RayzCameraDesc cd = t.camera.desc();
+    RayzRenderParams p = t.params(7);
+    p.chunk_spp = 2;
+    std::vector<float> a((size_t)p.width * p.height * 3), b(a.size());
+    std::vector<double> c(a.size());
+    RayzRenderStats st{};
+    int rc = rayz_oracle_render_b_f32(&sd, &cd, &p, nullptr, 0, a.data(), &st, 2);
+    p.traversal = RAYZ_TRAVERSAL_BVH;
+    rc |= rayz_oracle_render_b_f32(&sd, &cd, &p, nullptr, 0, b.data(), &st, 2);
+    p.precision = RAYZ_PRECISION_F64;
+    rc |= rayz_oracle_render_b_f64(&sd, &cd, &p, nullptr, 0, c.data(), &st, 2);
+    uint64_t rng[4];
+    std::memcpy(rng, t.rng.s, 32);
+    p.tmin = 1e-10;
+    rc |= rayz_oracle_render_a(&sd, &cd, &p, 0, p.height, rng, 0, c.data(), nullptr, &st);
+    rc |= rayz_oracle_render_a(&sd, &cd, &p, 0, p.height, rng, 1, c.data(), nullptr, &st);
+    const rayz_bvh::FlatBvh tree = rayz_bvh::build(f.spheres, f.triangles);
+    size_t diff = 0;
+    for (size_t i = 0; i < a.size(); ++i) diff += a[i] != b[i];
+    std::printf("%s: rc %d, %zu nodes, depth %u, flat-vs-bvh differing values %zu\n", name, rc, tree.nodes.size(), tree.depth, diff);
+    bool threw = false;
+    try {
+        t.render();
+    } catch (const rayz::GpuRenderFailed&) {
+        threw = true;
+    }
+    return rc != 0 || !threw || diff > a.size() / 100;
+}
+
+int main() {
+    const uint64_t seed = 5;
+    int bad = 0;
+    rayz::Tracer t1 = rayz::randomBouncing(48, -4, 4, &seed);
+    bad |= run(t1, "randomBouncing");
+    rayz::Tracer t2 = rayz::threeSpheres(40, &seed);
+    bad |= run(t2, "threeSpheres");
+    rayz::Tracer t3 = rayz::triangleMesh(40, 6, &seed);
+    bad |= run(t3, "triangleMesh");
+    rayz::Tracer t4 = rayz::Tracer::init(24, 30, 1, 0, rayz::V3{0, 0, 2}, rayz::V3{}, rayz::V3::y_hat(), &seed);
+    bad |= run(t4, "empty pool");
+    FILE* f = std::fopen("/dev/null", "w");
+    t1.img.writePPM(f);
+    std::fclose(f);
+    std::printf(bad ? "FAILED\n" : "sanitizer run ok\n");
+    return bad;
+}
