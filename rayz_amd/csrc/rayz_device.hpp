@@ -303,7 +303,7 @@ template <class R, int CLS> struct ScanGroup;
 // R = float) whose scalar operand is an SGPR PAIR — the same field of two neighbouring spheres.  Measured on
 // gfx950 (tools/ubench): a VALU instruction that reads a different SGPR each time issues at ≈2.75 cycles, not 2,
 // so the 7 scalar reads of a test bound the scalar-FMA form at ≈21 ticks per wave-test; the packed form needs
-// 2.5 pair reads per test and runs at 14.7.  Every half of a packed FMA is an ordinary IEEE FMA: results are
+// 3.5 pair reads per test and runs at 14.7.  Every half of a packed FMA is an ordinary IEEE FMA: results are
 // bit-identical to the scalar form (and to the oracle).
 template <class R> struct ScanGroup<R, 0> { // static
     typedef typename VecOf<R>::pair pr;
