@@ -96,6 +96,23 @@ template <int MODE> __global__ __launch_bounds__(256) void k2(int tiles, int str
                         cnt++;
                     }
                 }
+        } else if (MODE >= 2) { // MODE 2: square test max(|p1|,|p2|) <= b; MODE 3: disc test; groups of 4 rows, park (tile, block, group)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float q[4];
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    q[v] = MODE == 2 ? __builtin_fmaxf(__builtin_fabsf(p1[4 * g + v]), __builtin_fabsf(p2[4 * g + v]))
+                                     : __builtin_fmaf(p2[4 * g + v], p2[4 * g + v], p1[4 * g + v] * p1[4 * g + v]);
+                const float mn = __builtin_fminf(__builtin_fminf(q[0], q[1]), __builtin_fminf(q[2], q[3]));
+                const unsigned long long m = __ballot(mn <= bound);
+                if (m != 0ull) {
+                    if (__builtin_amdgcn_inverse_ballot_w64(m)) {
+                        list[256 * (cnt & 31u)] = id + 4 * g;
+                        cnt++;
+                    }
+                }
+            }
         } else {
             float q[16];
             float mn = 3.0e38f;
@@ -201,5 +218,7 @@ int main() {
     run<1, 0>("4 MFMA + mul/fma/min, slow path per lane", A, B, stream_tiles);
     run<0, 1>("pipelined, per-element uniform branch", A, B, stream_tiles);
     run<1, 1>("pipelined, min-reduce, park (tile,block)", A, B, stream_tiles);
+    run<2, 1>("pipelined, square test, park groups of 4", A, B, stream_tiles);
+    run<3, 1>("pipelined, disc test, park groups of 4", A, B, stream_tiles);
     return 0;
 }
