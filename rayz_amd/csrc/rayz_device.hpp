@@ -860,14 +860,30 @@ __device__ __forceinline__ bool bvh_box_hit(typename VecOf<R>::type lo, typename
     return t1 * Slack<R>::v >= t0;
 }
 
+// A lane parks hit leaves for phase L in `leaf` (and `leaf2` when RAYZ_BVH_LEAF_SLOTS is 2); with no slot free the
+// descriptor goes to the stack.  More slots = lanes keep stepping longer between phases (higher lane utilisation) at
+// the price of a staler tbest (more box tests).
+#ifndef RAYZ_BVH_LEAF_SLOTS
+#define RAYZ_BVH_LEAF_SLOTS 1
+#endif
+__device__ __forceinline__ bool bvh_slots_full(uint32_t leaf, uint32_t leaf2) {
+    return RAYZ_BVH_LEAF_SLOTS == 2 ? leaf2 != 0u : leaf != 0u;
+}
+template <class R>
+__device__ __forceinline__ void bvh_park(uint32_t desc, uint32_t& leaf, uint32_t& leaf2, BvhQuery<R>& q, uint32_t* stack) {
+    if (leaf == 0u) leaf = desc;
+    else if (RAYZ_BVH_LEAF_SLOTS == 2 && leaf2 == 0u) leaf2 = desc;
+    else stack[256 * q.sp++] = desc | kBvhLeafFlag;
+}
+
 // Phase N — one step of a lane: fetch an inner node's record, slab-test both children, then
 //   * a hit leaf child is PARKED in `leaf` for phase L (a second hit leaf goes to the stack),
 //   * hit inner children: continue into the nearer, push the farther,
 //   * nothing to continue with: pop.
 // `stack` is this lane's column of the workgroup's LDS stack (entry s at stack[s * 256]).
 template <class R>
-__device__ __forceinline__ void bvh_node_step(const DevScene<R>& sc, BvhQuery<R>& q, uint32_t& leaf, V<R> o, R tmin,
-                                              uint32_t* stack, uint32_t& node_tests) {
+__device__ __forceinline__ void bvh_node_step(const DevScene<R>& sc, BvhQuery<R>& q, uint32_t& leaf, uint32_t& leaf2, V<R> o,
+                                              R tmin, uint32_t* stack, uint32_t& node_tests) {
     typedef typename VecOf<R>::type r4;
     const r4* p = sc.bvh_nodes + 4 * (size_t)q.cur;
     const r4 llo = p[0], lhi = p[1], rlo = p[2], rhi = p[3];
@@ -884,15 +900,11 @@ __device__ __forceinline__ void bvh_node_step(const DevScene<R>& sc, BvhQuery<R>
         far = t;
     }
     if (far != kBvhDone) stack[256 * q.sp++] = far;
-    // leaf children
+    // leaf children: parked in the lane's free slots (the caller guarantees at least one), the rest on the stack
     const uint32_t l0 = (hl && lleaf != 0u) ? lleaf : 0u, l1 = (hr && rleaf != 0u) ? rleaf : 0u;
-    if (l0 != 0u && l1 != 0u) { // both: test one now, keep the other on the stack
-        stack[256 * q.sp++] = l1 | kBvhLeafFlag;
-        leaf = l0;
-    } else if ((l0 | l1) != 0u) {
-        leaf = l0 | l1;
-    }
-    if (near != kBvhDone && leaf != 0u) { // cannot walk on while a leaf is parked: defer the inner child too
+    if (l0 != 0u) bvh_park(l0, leaf, leaf2, q, stack);
+    if (l1 != 0u) bvh_park(l1, leaf, leaf2, q, stack);
+    if (near != kBvhDone && bvh_slots_full(leaf, leaf2)) { // cannot walk on with every slot taken: defer the inner child too
         stack[256 * q.sp++] = near;
         near = kBvhDone;
     }
@@ -900,11 +912,14 @@ __device__ __forceinline__ void bvh_node_step(const DevScene<R>& sc, BvhQuery<R>
 }
 
 // Pop until an inner node is found (→ q.cur) or a leaf descriptor is found (→ parked in `leaf`) or the stack is empty.
-template <class R> __device__ __forceinline__ void bvh_pop(BvhQuery<R>& q, uint32_t& leaf, const uint32_t* stack) {
+template <class R>
+__device__ __forceinline__ void bvh_pop(BvhQuery<R>& q, uint32_t& leaf, uint32_t& leaf2, const uint32_t* stack) {
     if (q.sp != 0u) {
         const uint32_t e = stack[256 * --q.sp];
-        if (e & kBvhLeafFlag) leaf = e & ~kBvhLeafFlag;
-        else q.cur = e;
+        if (e & kBvhLeafFlag) {
+            if (leaf == 0u) leaf = e & ~kBvhLeafFlag;
+            else leaf2 = e & ~kBvhLeafFlag;
+        } else q.cur = e;
     }
 }
 
@@ -985,6 +1000,14 @@ template <class R> __global__ __launch_bounds__(256, 5) void trace_kernel_bvh(co
     uint32_t item = 0, px = 0, py = 0, s_cur = 0, s_end = 0, seg = 0, nseg = 0, node_tests = 0, sphere_tests = 0;
     bool has_item = false, alive = false;
     bool queue_empty = false; // wave-uniform
+#ifdef RAYZ_BVH_PROFILE
+    unsigned long long pt[5] = {0, 0, 0, 0, 0}, pl[7] = {0, 0, 0, 0, 0, 0, 0}, pt0 = __builtin_amdgcn_s_memtime();
+#define RAYZ_PROF_T(k) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); pt[k] += now_ - pt0; pt0 = now_; }
+#define RAYZ_PROF_L(k, n) { pl[k] += (unsigned long long)(n); pl[k + 1] += 1; }
+#else
+#define RAYZ_PROF_T(k)
+#define RAYZ_PROF_L(k, n)
+#endif
 
     for (;;) {
         // ---- retire finished chunks, refill idle lanes (wave-aggregated queue pop) ----
@@ -1029,37 +1052,59 @@ template <class R> __global__ __launch_bounds__(256, 5) void trace_kernel_bvh(co
             bvh_begin<R>(q, d, n_nodes);
         }
         if (__ballot(alive) == 0ull) break;
+        RAYZ_PROF_T(0)
 
         // ---- rounds of (N) box steps, (L) leaf tests, (C) candidate roots ----
         const int n_alive = __popcll(__ballot(alive));
         for (;;) {
-            uint32_t leaf = 0;
+            uint32_t leaf = 0, leaf2 = 0;
             for (;;) { // phase N
                 // a lane with nothing in hand takes its next entry off the stack (an inner node, or a parked leaf)
-                if (alive && leaf == 0u && q.cur == kBvhDone) bvh_pop<R>(q, leaf, stack);
-                const bool can_step = alive && q.cur != kBvhDone && leaf == 0u;
+                if (alive && q.cur == kBvhDone && !bvh_slots_full(leaf, leaf2)) bvh_pop<R>(q, leaf, leaf2, stack);
+                const bool can_step = alive && q.cur != kBvhDone && !bvh_slots_full(leaf, leaf2);
                 const int n_can = __popcll(__ballot(can_step));
                 if (n_can == 0) break;
                 if (n_can < keep_stepping && __ballot(leaf != 0u) != 0ull) break;
-                if (can_step) bvh_node_step<R>(A.sc, q, leaf, o, A.tmin, stack, node_tests);
+                RAYZ_PROF_L(0, n_can)
+                if (can_step) bvh_node_step<R>(A.sc, q, leaf, leaf2, o, A.tmin, stack, node_tests);
             }
+            RAYZ_PROF_T(1)
             if (__ballot(leaf != 0u) == 0ull) break; // nobody parked: every walking lane ran out of nodes
-            uint32_t cand0 = 0, cand1 = 0;
+            RAYZ_PROF_L(2, __popcll(__ballot(leaf != 0u)))
+            uint32_t cand0 = 0, cand1 = 0, cand2 = 0, cand3 = 0;
             if (leaf != 0u) { // phase L
                 sphere_tests += leaf & 3u;
                 cand0 = bvh_leaf_entry<R>(A.sc, q, leaf, 0u, o, d, ud, time, A.tmin);
                 if ((leaf & 3u) > 1u) cand1 = bvh_leaf_entry<R>(A.sc, q, leaf, 1u, o, d, ud, time, A.tmin);
             }
-            if (__ballot((cand0 | cand1) != 0u) != 0ull) { // phase C
+            if (RAYZ_BVH_LEAF_SLOTS == 2 && __ballot(leaf2 != 0u) != 0ull) {
+                if (leaf2 != 0u) {
+                    sphere_tests += leaf2 & 3u;
+                    cand2 = bvh_leaf_entry<R>(A.sc, q, leaf2, 0u, o, d, ud, time, A.tmin);
+                    if ((leaf2 & 3u) > 1u) cand3 = bvh_leaf_entry<R>(A.sc, q, leaf2, 1u, o, d, ud, time, A.tmin);
+                }
+            }
+            RAYZ_PROF_T(2)
+            if (__ballot((cand0 | cand1 | cand2 | cand3) != 0u) != 0ull) { // phase C
+                RAYZ_PROF_L(4, __popcll(__ballot((cand0 | cand1 | cand2 | cand3) != 0u)))
                 if (cand0 != 0u) bvh_candidate<R>(A.sc, q, cand0 - 1u, o, d, time, A.tmin);
                 if (cand1 != 0u) bvh_candidate<R>(A.sc, q, cand1 - 1u, o, d, time, A.tmin);
+                if (RAYZ_BVH_LEAF_SLOTS == 2) {
+                    if (cand2 != 0u) bvh_candidate<R>(A.sc, q, cand2 - 1u, o, d, time, A.tmin);
+                    if (cand3 != 0u) bvh_candidate<R>(A.sc, q, cand3 - 1u, o, d, time, A.tmin);
+                }
             }
+            RAYZ_PROF_T(3)
             const int n_walking = __popcll(__ballot(alive && (q.cur != kBvhDone || q.sp != 0u)));
             if (n_walking == 0) break;
             if (n_walking < keep_active && n_walking < n_alive) break; // finished lanes wait: go shade / refill them
         }
 
         // ---- shade lanes whose query is complete ----
+        RAYZ_PROF_T(1)
+#ifdef RAYZ_BVH_PROFILE
+        pl[6] += __ballot(alive && q.cur == kBvhDone && q.sp == 0u) != 0ull ? 1ull : 0ull; // shade passes
+#endif
         if (alive && q.cur == kBvhDone && q.sp == 0u) {
             nseg++;
             seg++;
@@ -1071,7 +1116,15 @@ template <class R> __global__ __launch_bounds__(256, 5) void trace_kernel_bvh(co
                 bvh_begin<R>(q, d, n_nodes);
             }
         }
+        RAYZ_PROF_T(4)
     }
+#ifdef RAYZ_BVH_PROFILE
+    RAYZ_PROF_T(4)
+    if (lane == 0) {
+        for (int k = 0; k < 5; ++k) atomicAdd(&A.counters[4 + k], pt[k]);
+        for (int k = 0; k < 7; ++k) atomicAdd(&A.counters[9 + k], pl[k]);
+    }
+#endif
     unsigned long long t0 = nseg, t1 = node_tests, t2 = sphere_tests;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {

@@ -435,7 +435,7 @@ int render_impl(RayzScene* s, SceneBuffers<R>& b, const RayzCameraDesc* cam, con
         HIP_TRY(hipMalloc(&s->partial, need));
         s->partial_bytes = need;
     }
-    if (!s->counters) HIP_TRY(hipMalloc((void**)&s->counters, 4 * sizeof(unsigned long long)));
+    if (!s->counters) HIP_TRY(hipMalloc((void**)&s->counters, 16 * sizeof(unsigned long long)));
     if (!s->ev0) {
         HIP_TRY(hipEventCreate(&s->ev0));
         HIP_TRY(hipEventCreate(&s->ev1));
@@ -505,7 +505,7 @@ int render_impl(RayzScene* s, SceneBuffers<R>& b, const RayzCameraDesc* cam, con
     const uint64_t want = (items64 + per_block - 1) / per_block;
     if (grid > want) grid = want;
 
-    HIP_TRY(hipMemsetAsync(s->counters, 0, 4 * sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(s->counters, 0, 16 * sizeof(unsigned long long), stream));
     HIP_TRY(hipEventRecord(s->ev0, stream));
     if (use_bvh) hipLaunchKernelGGL(trace_kernel_bvh<R>, dim3((uint32_t)grid), dim3(256), 0, stream, A);
     else hipLaunchKernelGGL(lin, dim3((uint32_t)grid), dim3(256), 0, stream, A);
@@ -662,8 +662,19 @@ int rayz_hip_scene_sync(RayzScene* s, RayzRenderStats* stats) {
     if (g_device < 0) return fail(RAYZ_ERR_NO_DEVICE, "rayz_hip_init has not succeeded");
     HIP_TRY(hipStreamSynchronize(s->last_stream ? s->last_stream : g_stream));
     if (s->rendered) {
-        unsigned long long c[4] = {0, 0, 0, 0};
+        unsigned long long c[16] = {};
         HIP_TRY(hipMemcpy(c, s->counters, sizeof(c), hipMemcpyDeviceToHost));
+#ifdef RAYZ_BVH_PROFILE // measurement build only: per-phase wave time and lane occupancy of trace_kernel_bvh
+        if (s->last_bvh) {
+            const double tot = (double)(c[4] + c[5] + c[6] + c[7] + c[8]);
+            std::fprintf(stderr,
+                         "bvh phases (share of wave time | mean active lanes): refill %.1f%% | N %.1f%% %.1f | L %.1f%% %.1f | C %.1f%% "
+                         "%.1f | shade %.1f%% %.1f\n",
+                         100.0 * c[4] / tot, 100.0 * c[5] / tot, (double)c[9] / (double)(c[10] ? c[10] : 1), 100.0 * c[6] / tot,
+                         (double)c[11] / (double)(c[12] ? c[12] : 1), 100.0 * c[7] / tot, (double)c[13] / (double)(c[14] ? c[14] : 1),
+                         100.0 * c[8] / tot, (double)c[1] / (double)(c[15] ? c[15] : 1));
+        }
+#endif
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
         s->last.segments = c[1];

@@ -23,7 +23,8 @@ def bench(t, spp, reps=2):
 
 c3 = tracer.randomBouncing(1920, -50, 50, seed=42)
 c5 = tracer.triangleMesh(1920, 224, seed=1)
-for ka, ks in [(40, 24), (48, 32), (56, 40), (32, 16), (24, 12), (16, 8), (48, 16), (56, 8), (32, 32), (60, 48), (1, 1)]:
+pairs = [tuple(int(x) for x in a.split(',')) for a in sys.argv[1:]] or [(40, 24), (48, 32), (56, 40), (32, 16), (24, 12), (16, 8), (48, 16), (56, 8), (32, 32), (60, 48), (1, 1)]
+for ka, ks in pairs:
     os.environ["RAYZ_BVH_KEEP"] = f"{ka},{ks}"
     a, na = bench(c3, 256)
     b, nb = bench(c5, 128)
