@@ -159,6 +159,9 @@ def main():
     else:
         frame_segments = float(np.mean(seg_total))
         kernel_ms_avg = float(np.mean(kernel_ms))
+    # outside the timed region: the gathered frame must be a usable image (every rank holds all of it)
+    if not bool(torch.isfinite(fg.frame).all().item()) or bool((fg.frame < 0).any().item()):
+        raise SystemExit("bench.py: the rendered frame holds non-finite or negative radiance")
 
     # N = 1 only, after the timed region: the same frame through the reference's own accelerator (BVH traversal),
     # reported beside the headline (which stays the flat hit list BASELINE.json names)

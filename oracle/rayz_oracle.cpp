@@ -1007,7 +1007,8 @@ static PathResult<R> tracePath(const SceneB<R>& sc, const CamB<R>& cam, const Ra
             } else {                                                         // :189-194
                 const V<R> perp{fm(nrm.x, cosv, ud.x) * eta, fm(nrm.y, cosv, ud.y) * eta,
                                 fm(nrm.z, cosv, ud.z) * eta};
-                const R sp = -std::sqrt(R(1) - dot3(perp, perp));
+                // clamped at 0: see DESIGN.md §4.5 (f32 rounds 1 − |perp|² below 0 near the critical angle)
+                const R sp = -std::sqrt(std::fmax(R(1) - dot3(perp, perp), R(0)));
                 nd = {fm(nrm.x, sp, perp.x), fm(nrm.y, sp, perp.y), fm(nrm.z, sp, perp.z)};
             }
             att = {1, 1, 1};

@@ -663,7 +663,9 @@ __device__ __forceinline__ bool shade(const DevScene<R>& sc, Pcg32& g, V<R>& o, 
             nd = {fm(-k, nrm.x, d.x), fm(-k, nrm.y, d.y), fm(-k, nrm.z, d.z)};
         } else {
             const V<R> perp{fm(nrm.x, cosv, ud.x) * eta, fm(nrm.y, cosv, ud.y) * eta, fm(nrm.z, cosv, ud.z) * eta};
-            const R sp = -sq(R(1) - dot3(perp, perp));
+            // exact arithmetic has 1 − |perp|² ≥ 0 here (eta·sin ≤ 1); in f32 it rounds below 0 about once per 1e9
+            // samples and the reference's bare sqrt (src/material.zig:192) would make the pixel NaN: clamp at 0
+            const R sp = -sq(mx(R(1) - dot3(perp, perp), R(0)));
             nd = {fm(nrm.x, sp, perp.x), fm(nrm.y, sp, perp.y), fm(nrm.z, sp, perp.z)};
         }
         att = {R(1), R(1), R(1)};

@@ -204,3 +204,24 @@ def test_gpu_bvh_shards_and_custom_scene(gpu, oracle):
         part, _ = gpu.render_host(scene, cam, q)
         out[gpu.shard_row_indices(p.height, 4, idx, 3)] = part
     assert_images_equal(out, got, "BVH 3 shards")
+
+
+@pytest.mark.gpu
+def test_gpu_config4_full_frame_on_one_gpu(gpu, oracle):
+    """BASELINE configs[3] (3840x2160, 4096 spp, 10,003 spheres) in full on ONE GPU through the BVH kernel: 2.1e9
+    work items and a 34 GB chunk-sum workspace (the sizing DESIGN.md §5 claims for 288 GB parts).  16 scattered
+    pixels are checked bit for bit against the oracle at the same 4096 spp; counters obey their identities."""
+    t = tracer.randomBouncing(3840, -50, 50, seed=42)
+    t.samples_per_px = 4096
+    t.set_gpu(render_seed=1, traversal=capi.TRAVERSAL_BVH)
+    scene, cam, p = t.scene_desc(), t.camera_desc(), t.params()
+    assert (p.width, p.height) == (3840, 2160)
+    got, st = gpu.render_host(scene, cam, p)
+    assert got.shape == (2160, 3840, 3) and np.isfinite(got).all() and (got >= 0).all()
+    assert st.primary_rays == 3840 * 2160 * 4096
+    assert 2.0 < st.segments / st.primary_rays < 4.5 and st.node_tests > 20 * st.segments
+    rng = np.random.default_rng(4)
+    pix = np.unique(np.concatenate([rng.integers(0, 3840 * 2160, 14), [0, 3840 * 2160 - 1]])).astype(np.uint32)
+    want, _ = oracle.render_b(scene, cam, p, pixels=pix)
+    assert_images_equal(got.reshape(-1, 3)[pix], want, "config 4 spot pixels")
+    assert got[:80].mean() > got[-80:].mean()
