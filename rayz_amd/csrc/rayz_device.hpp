@@ -978,6 +978,9 @@ __device__ __forceinline__ void bvh_candidate(const DevScene<R>& sc, BvhQuery<R>
 // the order in which hittables are examined, so this scheduling changes no result — only how much pruning the
 // shrinking tbest achieves.  When too few lanes still have nodes to visit, the finished lanes are shaded and
 // refilled (ray regeneration) while the others keep their query state and resume.
+#ifndef RAYZ_STAT_SPILL
+#define RAYZ_STAT_SPILL 0x7fffffffu // tests build with a small value to exercise the spill
+#endif
 constexpr int kBvhKeepActive = 24;   // rounds continue while at least this many lanes still walk
 constexpr int kBvhKeepStepping = 12; // phase N continues while at least this many lanes can take a box step
                                      // (defaults; TraceArgs::bvh_keep carries the values in use)
@@ -1041,6 +1044,13 @@ template <class R> __global__ __launch_bounds__(256, 5) void trace_kernel_bvh(co
                 acc = {R(0), R(0), R(0)};
             }
             if (base + n_need >= (unsigned long long)A.total_items) queue_empty = true;
+            // the per-lane u32 statistics would wrap after ≈30 minutes inside one launch: spill them when half full
+            if (__ballot(node_tests > RAYZ_STAT_SPILL) != 0ull) {
+                atomicAdd(&A.counters[2], (unsigned long long)node_tests);
+                atomicAdd(&A.counters[3], (unsigned long long)sphere_tests);
+                atomicAdd(&A.counters[1], (unsigned long long)nseg);
+                node_tests = sphere_tests = nseg = 0;
+            }
         }
         if (!alive && has_item) {
             const unsigned long long pixel_index = (unsigned long long)py * A.width + px;
