@@ -271,6 +271,11 @@ def test_full_size_config3_spot_pixels_and_counters(gpu, oracle):
     assert_images_equal(got.reshape(-1, 3)[pix], want, "full-size spot pixels")
     # sky rows are brighter than ground rows, and the image is not constant
     assert got[:40].mean() > got[-40:].mean() and got.std() > 0.05
+    # codegen guard: the scan loop lives on a register-allocation edge (a refactor that made hipcc spill SGPRs inside
+    # the loop ran 30 % slower with identical images; this 32-spp frame normally gives ~203 Msamples/s) — fail loudly if that happens again
+    rate = st.primary_rays / st.kernel_ms / 1e3
+    print(f"flat-list scan: {rate:.1f} Msamples/s at 32 spp")
+    assert rate > 170.0, f"flat-list kernel at {rate:.1f} Msamples/s: check SGPR spills in trace_kernel's scan loop"
 
 
 def test_measurement_variants_are_bit_identical(gpu, oracle, monkeypatch):
