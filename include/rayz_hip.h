@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RAYZ_HIP_ABI_VERSION 2u
+#define RAYZ_HIP_ABI_VERSION 3u
 
 typedef enum RayzStatus {
     RAYZ_OK = 0,
@@ -58,8 +58,10 @@ typedef enum RayzPrecision {
 
 typedef enum RayzTraversal {
     RAYZ_TRAVERSAL_LINEAR = 0, /* flat hit list: every sphere tested per segment (north star) */
-    RAYZ_TRAVERSAL_BVH = 1     /* the reference's accelerator, src/hit.zig:101-217 */
+    RAYZ_TRAVERSAL_BVH = 1,    /* the reference's accelerator, src/hit.zig:101-217 */
+    RAYZ_TRAVERSAL_AUTO = 2    /* flat list up to RAYZ_AUTO_BVH_MIN hittables, BVH above (same image either way) */
 } RayzTraversal;
+#define RAYZ_AUTO_BVH_MIN 768u /* measured crossover on MI355X: tools/crossover.py */
 
 /* One entry of `MemPool.textures` (src/ecs.zig:26): SolidTexture src/material.zig:19-25 or
  * CheckerTexture src/material.zig:27-39.  `even`/`odd` are TextureHandle.idx values. */

@@ -24,9 +24,8 @@ _lib = None
 
 
 def build(force: bool = False) -> str:
-    src = os.path.join(HERE, "rayz_oracle.cpp")
-    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
-        subprocess.run(["make", "-C", HERE, "-B" if force else "-s"], check=True)
+    # make decides (the library depends on rayz_oracle.cpp AND include/rayz_hip.h)
+    subprocess.run(["make", "-C", HERE, "-s"] + (["-B"] if force else []), check=True)
     return LIB_PATH
 
 

@@ -789,6 +789,11 @@ template <class R> static V<R> textureValue(const SceneB<R>& sc, u32 idx, V<R> p
     return V<R>{0, 0, 0};
 }
 
+// RAYZ_TRAVERSAL_AUTO (include/rayz_hip.h): flat list up to RAYZ_AUTO_BVH_MIN hittables, BVH above
+static inline bool useBvh(const RayzRenderParams& p, u32 n_hittables) {
+    return p.traversal == RAYZ_TRAVERSAL_BVH || (p.traversal == RAYZ_TRAVERSAL_AUTO && n_hittables > RAYZ_AUTO_BVH_MIN);
+}
+
 template <class R> struct PathResult {
     V<R> L;
     u32 segments;
@@ -902,7 +907,7 @@ static PathResult<R> tracePath(const SceneB<R>& sc, const CamB<R>& cam, const Ra
                 ibest = (int)prim;
             }
         };
-        if (p.traversal == RAYZ_TRAVERSAL_BVH) {
+        if (useBvh(p, (u32)(sc.sph.size() + sc.tri.size()))) {
             // src/hit.zig:181-216 as a skip-link walk; slab test src/hit.zig:70-98 with 1/d hoisted and a
             // 4-ulp slack (never culls a box the f64 narrow phase would hit)
             const V<R> inv{R(1) / d.x, R(1) / d.y, R(1) / d.z};
@@ -1039,7 +1044,7 @@ static int render(const RayzSceneDesc* sd, const RayzCameraDesc* cd, const RayzR
     const RayzRenderParams p = *pp;
     if (!p.width || !p.height || !p.samples_per_px) return RAYZ_ERR_BAD_ARG;
     SceneB<R> sc = buildScene<R>(*sd);
-    if (p.traversal == RAYZ_TRAVERSAL_BVH) buildBvh<R>(*sd, sc);
+    if (useBvh(*pp, sd->n_spheres + sd->n_triangles)) buildBvh<R>(*sd, sc);
     const CamB<R> cam = buildCamera<R>(*cd);
     const u32 C = p.chunk_spp ? p.chunk_spp : 16;
     std::vector<u32> pixels; // global pixel indices, in output order

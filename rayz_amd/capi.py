@@ -12,7 +12,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "librayz_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 OK = 0
 ERR_BAD_ARG = -1
@@ -25,7 +25,7 @@ TEX_CHECKER, TEX_SOLID = 0, 1
 MAT_DIFFUSE, MAT_METALLIC, MAT_DIELECTRIC = 0, 1, 2
 DIFFUSE_UNIT_SPHERE, DIFFUSE_UNIT_SPHERE_SURFACE, DIFFUSE_HEMISPHERE = 0, 1, 2
 PRECISION_F32, PRECISION_F64 = 0, 1
-TRAVERSAL_LINEAR, TRAVERSAL_BVH = 0, 1
+TRAVERSAL_LINEAR, TRAVERSAL_BVH, TRAVERSAL_AUTO = 0, 1, 2
 
 D3 = C.c_double * 3
 

@@ -368,7 +368,7 @@ int validate_params(const RayzRenderParams* p) {
     if (!p) return fail(RAYZ_ERR_BAD_ARG, "params is null");
     if (!p->width || !p->height || !p->samples_per_px) return fail(RAYZ_ERR_BAD_ARG, "width, height and samples_per_px must be > 0");
     if (p->precision > RAYZ_PRECISION_F64) return fail(RAYZ_ERR_BAD_ARG, "bad precision %u", p->precision);
-    if (p->traversal > RAYZ_TRAVERSAL_BVH) return fail(RAYZ_ERR_BAD_ARG, "bad traversal %u", p->traversal);
+    if (p->traversal > RAYZ_TRAVERSAL_AUTO) return fail(RAYZ_ERR_BAD_ARG, "bad traversal %u", p->traversal);
     const uint32_t sc = p->shard_count ? p->shard_count : 1;
     if (p->shard_index >= sc) return fail(RAYZ_ERR_BAD_ARG, "shard_index %u >= shard_count %u", p->shard_index, sc);
     if (!(p->tmin == p->tmin)) return fail(RAYZ_ERR_BAD_ARG, "tmin is NaN");
@@ -393,7 +393,8 @@ int render_impl(RayzScene* s, SceneBuffers<R>& b, const RayzCameraDesc* cam, con
                 hipStream_t stream) {
     typedef typename VecOf<R>::type r4;
     if (g_device < 0) return fail(RAYZ_ERR_NO_DEVICE, "rayz_hip_init has not succeeded");
-    const bool use_bvh = p->traversal == RAYZ_TRAVERSAL_BVH;
+    const bool use_bvh = p->traversal == RAYZ_TRAVERSAL_BVH ||
+                         (p->traversal == RAYZ_TRAVERSAL_AUTO && s->spheres.size() + s->triangles.size() > RAYZ_AUTO_BVH_MIN);
     if (s->spheres.size() + s->triangles.size() >= (1u << 27))
         return fail(RAYZ_ERR_BAD_ARG, "too many hittables for the device layout");
     int rc = upload<R>(s, b);

@@ -315,7 +315,7 @@ struct GpuRenderFailed : std::runtime_error {
 // What the MI355X path adds to the reference's Tracer fields (none of these exist in src/renderer.zig).
 struct GpuOptions {
     RayzPrecision precision = RAYZ_PRECISION_F32;
-    RayzTraversal traversal = RAYZ_TRAVERSAL_LINEAR;
+    RayzTraversal traversal = RAYZ_TRAVERSAL_AUTO; // the reference always walks its BVH; AUTO picks what is faster here
     double tmin = -1;         // < 0: 1e-3 for f32 (1e-10 is unusable in f32), the reference's 1e-10 for f64
     bool has_render_seed = false;
     uint64_t render_seed = 0; // else drawn from `rng` when render() starts

@@ -4,7 +4,7 @@
 //
 // Extras the reference does not have (environment variables, so the positional interface stays the
 // reference's): RAYZ_SPP, RAYZ_BOUNCES, RAYZ_SEED, RAYZ_GRID (half-width of the sphere grid, 11 in the
-// reference), RAYZ_PRECISION=f32|f64, RAYZ_TRAVERSAL=linear|bvh.
+// reference), RAYZ_PRECISION=f32|f64, RAYZ_TRAVERSAL=linear|bvh|auto (default auto).
 #include "rayz.hpp"
 
 #include <chrono>
@@ -32,7 +32,8 @@ int main(int argc, char** argv) {
     if ((e = std::getenv("RAYZ_SPP"))) tracer.samples_per_px = std::strtoul(e, nullptr, 10);
     if ((e = std::getenv("RAYZ_BOUNCES"))) tracer.max_bounces = std::strtoul(e, nullptr, 10);
     if ((e = std::getenv("RAYZ_PRECISION")) && std::string(e) == "f64") tracer.gpu.precision = RAYZ_PRECISION_F64;
-    if ((e = std::getenv("RAYZ_TRAVERSAL")) && std::string(e) == "bvh") tracer.gpu.traversal = RAYZ_TRAVERSAL_BVH;
+    if ((e = std::getenv("RAYZ_TRAVERSAL")))
+        tracer.gpu.traversal = std::string(e) == "bvh" ? RAYZ_TRAVERSAL_BVH : std::string(e) == "linear" ? RAYZ_TRAVERSAL_LINEAR : RAYZ_TRAVERSAL_AUTO;
 
     if (rayz_hip_init(0) != RAYZ_OK) {
         std::fprintf(stderr, "error: GpuRenderFailed: %s\n", rayz_hip_last_error());

@@ -50,9 +50,9 @@ def test_config2_scene_random_bouncing(gpu, oracle):
 
 def test_config3_scene_10k_spheres(gpu, oracle):
     """configs[2]'s scene (grid [-50,50): ~10k spheres) at 64x36x4: every scan stream, pad and prefetch path."""
-    t = tracer.randomBouncing(64, -50, 50, seed=42)
+    t = tracer.randomBouncing(64, -50, 50, seed=42)  # > RAYZ_AUTO_BVH_MIN hittables: ask for the flat list explicitly
     t.samples_per_px = 4
-    t.set_gpu(render_seed=1)
+    t.set_gpu(render_seed=1, traversal=capi.TRAVERSAL_LINEAR)
     got, want, gst, ost = _pair(gpu, oracle, t)
     assert_images_equal(got, want, "10k spheres 64x36x4")
     assert gst.segments == ost.segments and gst.sphere_tests == ost.segments * t.info().n_spheres
@@ -251,6 +251,20 @@ def test_tonemap_u8_matches_write_ppm(gpu, oracle):
     assert (out.cpu().numpy().reshape(64, 64, 3) == img.to_u8()).all()
 
 
+def test_traversal_auto_picks_by_scene_size(gpu, oracle):
+    """RAYZ_TRAVERSAL_AUTO (the host mirror's default; the reference always walks its BVH): flat list up to
+    RAYZ_AUTO_BVH_MIN = 768 hittables, BVH above; the oracle resolves AUTO the same way and images match bit for bit."""
+    small, big = tracer.randomBouncing(64, seed=42), tracer.randomBouncing(64, -14, 14, seed=42)
+    assert small.info().n_spheres <= 768 < big.info().n_spheres
+    for t, bvh in ((small, False), (big, True)):
+        t.samples_per_px = 4
+        t.set_gpu(render_seed=3)
+        assert t.params().traversal == capi.TRAVERSAL_AUTO
+        got, want, gst, ost = _pair(gpu, oracle, t)
+        assert_images_equal(got, want, f"auto traversal, bvh={bvh}")
+        assert (gst.node_tests > 0) == bvh and (ost.node_tests > 0) == bvh and gst.segments == ost.segments
+
+
 # ---- BASELINE.json's full size: size-independent properties + oracle spot pixels -------------------------
 def test_full_size_config3_spot_pixels_and_counters(gpu, oracle):
     """configs[2] geometry at full resolution (1920x1080, ~10k spheres); spp reduced to 32 to bound the test's GPU
@@ -258,7 +272,7 @@ def test_full_size_config3_spot_pixels_and_counters(gpu, oracle):
     same 32 spp (≈0.5 G sphere tests on the CPU) and they must match bit for bit; counters obey their identities."""
     t = tracer.randomBouncing(1920, -50, 50, seed=42)
     t.samples_per_px = 32
-    t.set_gpu(render_seed=1)
+    t.set_gpu(render_seed=1, traversal=capi.TRAVERSAL_LINEAR)
     scene, cam, p = t.scene_desc(), t.camera_desc(), t.params()
     got, st = gpu.render_host(scene, cam, p)
     assert got.shape == (1080, 1920, 3) and np.isfinite(got).all() and (got >= 0).all()

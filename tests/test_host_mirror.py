@@ -18,7 +18,7 @@ def test_tracer_defaults_match_reference(built):
         assert (i.width, i.height) == (w, h)
         assert (i.samples_per_px, i.max_bounces) == (10, 50)
         p = t.params()
-        assert p.tmin == 1e-3 and p.precision == capi.PRECISION_F32 and p.traversal == capi.TRAVERSAL_LINEAR
+        assert p.tmin == 1e-3 and p.precision == capi.PRECISION_F32 and p.traversal == capi.TRAVERSAL_AUTO
     t.set_gpu(precision=capi.PRECISION_F64)
     assert t.params().tmin == 1e-10  # the reference's own tmin, src/renderer.zig:107
 
