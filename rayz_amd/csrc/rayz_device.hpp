@@ -776,6 +776,12 @@ template <class R, int NR, bool SYNC> __global__ __launch_bounds__(256, NR == 1 
     for (int r = 0; r < NR; ++r) path_init<R>(p[r]);
     uint32_t nseg = 0;
     bool queue_empty = false; // wave-uniform
+#ifdef RAYZ_FLAT_PROFILE // measurement build only: wave time per phase (refill, ray setup, scan, narrow flush, shade)
+    unsigned long long ft[5] = {0, 0, 0, 0, 0}, ft0 = __builtin_amdgcn_s_memtime(), fiters = 0;
+#define RAYZ_FPROF(k) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ft[k] += now_ - ft0; ft0 = now_; }
+#else
+#define RAYZ_FPROF(k)
+#endif
 
     for (;;) {
         // ---- retire finished chunks, refill idle slots ----
@@ -789,6 +795,7 @@ template <class R, int NR, bool SYNC> __global__ __launch_bounds__(256, NR == 1 
             if (__syncthreads_or(any ? 1 : 0) == 0) break;
         } else if (__ballot(any) == 0ull) break; // queue drained and every slot idle: the wave is done
 
+        RAYZ_FPROF(0)
         // ---- nearest hit (full EXEC; idle tail slots recompute their last ray, results unused) ----
         ScanRay<R> ray[NR];
         V<R> ud[NR];
@@ -797,7 +804,19 @@ template <class R, int NR, bool SYNC> __global__ __launch_bounds__(256, NR == 1 
             ud[r] = unit(p[r].d);
             scan_begin<R, NR>(ray[r], p[r].o, p[r].d, ud[r], p[r].time);
         }
+        RAYZ_FPROF(1)
+#ifdef RAYZ_FLAT_PROFILE
+        fiters++;
+        scan_class<R, 0, NR>(A.sc, (int)A.sc.ns_pad, ray, A.tmin);
+        scan_class<R, 1, NR>(A.sc, (int)A.sc.ny_pad, ray, A.tmin);
+        scan_class<R, 2, NR>(A.sc, (int)A.sc.ng_pad, ray, A.tmin);
+        RAYZ_FPROF(2)
+        narrow_flush<R, NR>(A.sc, ray, A.tmin);
+        scan_triangles<R, NR>(A.sc, ray, A.tmin);
+        RAYZ_FPROF(3)
+#else
         scan_spheres<R, NR>(A.sc, ray, A.tmin);
+#endif
 
         // ---- shade ----
 #pragma unroll
@@ -810,7 +829,14 @@ template <class R, int NR, bool SYNC> __global__ __launch_bounds__(256, NR == 1 
                 if (p[r].seg >= A.max_bounces) cont = false; // depth exhausted → black, src/renderer.zig:104-105
                 p[r].alive = cont;
             }
+        RAYZ_FPROF(4)
     }
+#ifdef RAYZ_FLAT_PROFILE
+    if (lane == 0) {
+        for (int k = 0; k < 5; ++k) atomicAdd(&A.counters[4 + k], ft[k]);
+        atomicAdd(&A.counters[9], fiters);
+    }
+#endif
     // ---- counters: one atomic per wave ----
     unsigned long long tot = nseg;
 #pragma unroll

@@ -665,6 +665,14 @@ int rayz_hip_scene_sync(RayzScene* s, RayzRenderStats* stats) {
     if (s->rendered) {
         unsigned long long c[16] = {};
         HIP_TRY(hipMemcpy(c, s->counters, sizeof(c), hipMemcpyDeviceToHost));
+#ifdef RAYZ_FLAT_PROFILE // measurement build only: wave time per phase of trace_kernel
+        if (!s->last_bvh && c[9]) {
+            const double tot = (double)(c[4] + c[5] + c[6] + c[7] + c[8]);
+            std::fprintf(stderr, "flat phases (share of wave time; ticks per wave-iteration %.0f): refill %.1f%% | setup %.1f%% | scan %.1f%% | "
+                                 "flush %.1f%% | shade %.1f%%\n", tot / (double)c[9], 100.0 * c[4] / tot, 100.0 * c[5] / tot,
+                         100.0 * c[6] / tot, 100.0 * c[7] / tot, 100.0 * c[8] / tot);
+        }
+#endif
 #ifdef RAYZ_BVH_PROFILE // measurement build only: per-phase wave time and lane occupancy of trace_kernel_bvh
         if (s->last_bvh) {
             const double tot = (double)(c[4] + c[5] + c[6] + c[7] + c[8]);
