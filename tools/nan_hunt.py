@@ -27,7 +27,7 @@ else:
 t.samples_per_px = spp
 if len(sys.argv) > 6:
     t.max_bounces = int(sys.argv[6])
-t.set_gpu(render_seed=1, traversal=capi.TRAVERSAL_BVH if trav == "bvh" else capi.TRAVERSAL_LINEAR,
+t.set_gpu(render_seed=int(os.environ.get("RAYZ_HUNT_SEED", "1")), traversal=capi.TRAVERSAL_BVH if trav == "bvh" else capi.TRAVERSAL_LINEAR,
           precision=capi.PRECISION_F64 if prec == "f64" else capi.PRECISION_F32)
 scene, cam, p = t.scene_desc(), t.camera_desc(), t.params()
 t0 = time.time()
