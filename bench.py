@@ -284,6 +284,16 @@ def main():
                         "peak": PEAK_HBM_GBPS, "unit": "GB/s"},
             },
         }
+        if args.traversal == "linear":
+            # SURVEY 8d "logical scan bytes": every segment reads every scan record once per LANE in the reference's
+            # formulation; the kernel reads it once per WAVE through the scalar cache (records: 16 B static, 20 B
+            # y-moving, 32 B moving) - served by K$ / L2, never HBM
+            rec = n_static * 16 + n_movy * 20 + (n_moving - n_movy) * 32
+            lane_bytes = frame_segments / world * rec
+            out["roofline"]["logical_scan"] = {
+                "per_lane_bytes": lane_bytes, "per_lane_TBps": lane_bytes / (kernel_ms_avg * 1e-3) / 1e12,
+                "scalar_cache_bytes": lane_bytes / 64, "scalar_cache_TBps": lane_bytes / 64 / (kernel_ms_avg * 1e-3) / 1e12,
+            }
         if also:
             out["also"] = also
         if not args.no_cpu_baseline and world == 1:
