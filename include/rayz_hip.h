@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RAYZ_HIP_ABI_VERSION 3u
+#define RAYZ_HIP_ABI_VERSION 3u /* 2: RayzTriangle, shard fields; 3: RAYZ_TRAVERSAL_AUTO */
 
 typedef enum RayzStatus {
     RAYZ_OK = 0,
