@@ -263,7 +263,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32 reject test + f64 candidate roots" if args.precision == "f32" else "f64",
+            "dtype": "f32" if args.precision == "f32" else "f64",
             "data": "synthetic",
             "config": {
                 "workload": f"randomBouncing grid [-{args.grid},{args.grid}) = {info.n_spheres} spheres "
@@ -271,6 +271,8 @@ def main():
                             f"{args.traversal} traversal, scene seed {args.scene_seed}, render seed {args.render_seed}",
                 "parallelism": f"row-interleaved shard x{world} + one RCCL all_gather per frame" if world > 1 else "1 GPU",
                 "segments_per_sample": frame_segments / samples_per_step,
+                "arithmetic": ("f32 path state and reject test, f64 candidate roots (DESIGN.md 4.3), tmin 1e-3"
+                               if args.precision == "f32" else "f64 throughout, tmin 1e-10 (the reference's scalar type)"),
             },
             "roofline": {
                 "bound": "valu_fp32" if args.precision == "f32" else "valu_fp64", "achieved": achieved, "peak": peak,
