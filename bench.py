@@ -116,25 +116,62 @@ def cpu_baseline(t, target_s: float):
     return out
 
 
+def launch_ranks(args) -> None:
+    """`python bench.py --gpus N` without a launcher: start N ranks under torch.distributed.run and exit with its
+    code.  Runs BEFORE anything touches the GPU in this process (the parent only waits; `device_count()` does not
+    initialise HIP on this image).  Never prints a line for fewer GPUs than were asked for."""
+    import socket
+    import subprocess
+
+    import torch
+
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible; refusing to measure fewer")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    print("bench.py: WORLD_SIZE unset, launching " + " ".join(cmd), file=sys.stderr, flush=True)
+    raise SystemExit(subprocess.run(cmd).returncode)
+
+
 def main():
     args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        launch_ranks(args)  # does not return
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:  # never report n_gpus different from what was asked for
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+
     import numpy as np
     import torch
     import torch.distributed as dist
 
     from rayz_amd import capi, render, tracer
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) are visible")
     torch.cuda.set_device(local_rank)
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = dist.get_backend()
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
+        # one rank per physical GPU: every rank must sit on a different device
+        ident = [None] * world
+        dist.all_gather_object(ident, (os.uname().nodename, str(torch.cuda.get_device_properties(local_rank).uuid)))
+        if len(set(ident)) != world:
+            raise SystemExit(f"bench.py: ranks share a GPU: {ident}")
     render.init(local_rank)
 
     # ---- workload: same generator and seeds on every rank (the scene is replicated, 320 KB) ----
@@ -270,6 +307,7 @@ def main():
                             f"({n_static} static, {n_moving} moving), {W}x{H}, {args.spp} spp, {args.bounces} bounces, "
                             f"{args.traversal} traversal, scene seed {args.scene_seed}, render seed {args.render_seed}",
                 "parallelism": f"row-interleaved shard x{world} + one RCCL all_gather per frame" if world > 1 else "1 GPU",
+                "collective_backend": backend, "collective_world_size": world if world > 1 else None,
                 "segments_per_sample": frame_segments / samples_per_step,
                 "arithmetic": ("f32 path state and reject test, f64 candidate roots (DESIGN.md 4.3), tmin 1e-3"
                                if args.precision == "f32" else "f64 throughout, tmin 1e-10 (the reference's scalar type)"),
