@@ -25,7 +25,9 @@
 extern "C" {
 #endif
 
-#define RAYZ_HIP_ABI_VERSION 3u /* 2: RayzTriangle, shard fields; 3: RAYZ_TRAVERSAL_AUTO */
+#define RAYZ_HIP_ABI_VERSION 4u /* 2: RayzTriangle, shard fields; 3: RAYZ_TRAVERSAL_AUTO; 4: per-scene devices,
+                                   rayz_hip_multi_* (several GPUs behind one call), rayz_hip_kat, chunk_spp auto */
+#define RAYZ_MAX_DEVICES 64
 
 typedef enum RayzStatus {
     RAYZ_OK = 0,
@@ -162,8 +164,12 @@ typedef struct RayzRenderStats {
 
 typedef struct RayzScene RayzScene; /* opaque: device-resident scene + workspace */
 
-/* Library / device lifetime.  `device` is the HIP ordinal this process renders on
- * (one process per GPU).  Idempotent. */
+/* Library / device lifetime.  rayz_hip_init(device) creates the context of that HIP ordinal (its stream, CU count;
+ * gfx950 only) and makes it the DEFAULT device: the one the entry points without a device argument use.  Idempotent;
+ * calling it for a second ordinal adds a context and moves the default, it does not re-target existing scenes —
+ * a scene stays on the device it was bound to.  Every entry point selects its device itself and restores the
+ * calling thread's current HIP device on return.  rayz_hip_shutdown destroys all contexts (scenes must be
+ * destroyed first; a scene destroyed later still frees its memory). */
 int rayz_hip_init(int device);
 void rayz_hip_shutdown(void);
 const char* rayz_hip_last_error(void);
@@ -172,9 +178,18 @@ uint32_t rayz_hip_abi_version(void);
 /* Number of rows the shard described by `p` owns (= rows of the compact output). */
 uint32_t rayz_hip_shard_rows(const RayzRenderParams* p);
 
+/* samples per work item the render of `p` will use: p->chunk_spp, or the default when that is 0.  Part of the
+ * image's definition; independent of the shard fields. */
+uint32_t rayz_hip_chunk_spp(const RayzRenderParams* p);
+
 /* Replaces src/renderer.zig:76-78 (initHittables + BVH build) and what follows it: validates the
- * handles, lays the pool out in HBM and (for BVH traversal) builds the reference's BVH on the host. */
+ * handles (RAYZ_ERR_BAD_ARG for an index out of range, a checker chain that contains a cycle or nests deeper than
+ * 8 lookups — the reference recurses without a limit, src/material.zig:36-37, the device walks a bounded loop),
+ * lays the pool out in HBM and (for BVH traversal) builds the reference's BVH on the host.
+ * rayz_hip_scene_create binds the scene to the default device at its first render; _create_on binds it to
+ * `device` now (creating that device's context if needed).  One render in flight per scene. */
 int rayz_hip_scene_create(const RayzSceneDesc* scene, RayzScene** out);
+int rayz_hip_scene_create_on(int device, const RayzSceneDesc* scene, RayzScene** out);
 int rayz_hip_scene_destroy(RayzScene* scene);
 
 /* The BVH `render()` would build (src/renderer.zig:76-78 -> src/hit.zig:130-161), flattened in depth-first
@@ -205,10 +220,49 @@ int rayz_hip_render(const RayzSceneDesc* scene, const RayzCameraDesc* camera, co
 int rayz_hip_render_f64(const RayzSceneDesc* scene, const RayzCameraDesc* camera, const RayzRenderParams* params,
                         double* rgb_out, RayzRenderStats* stats_or_null);
 
+/* ---- several GPUs behind ONE call -------------------------------------------------------------------------
+ * The reference's caller makes one call, `tracer.render()` (src/rayz.zig:26, src/renderer.zig:72-101).  These
+ * entry points give that one call every GPU of the node: the pool is replicated (one scene per device), image
+ * rows are dealt to the devices in interleaved tiles of `params->tile_rows` rows (0 = 1: pure row interleave),
+ * each device traces its rows on its own stream, and ONE collective — an RCCL gather of the row tiles to
+ * devices[0] over xGMI (ncclCommInitAll + ncclGather), or peer copies — reassembles the frame, which is copied
+ * to the caller's HOST buffer (height*width*3, row-major RGB).  The image is bit-identical for any device count
+ * (the per-(pixel,sample) streams are keyed by global pixel coordinates).  `params->shard_index/shard_count`
+ * must be 0: the library shards.  Blocking; driven by the calling thread; one call at a time per handle. */
+typedef enum RayzGatherTransport {
+    RAYZ_GATHER_RCCL = 0,     /* ncclGather to devices[0] (librccl.so.1 is opened at the first multi-device call) */
+    RAYZ_GATHER_PEER_COPY = 1 /* hipMemcpyPeerAsync into devices[0] */
+} RayzGatherTransport;
+
+typedef struct RayzMulti RayzMulti; /* opaque: one scene per device + communicators + gather buffers */
+
+int rayz_hip_multi_create(const int* devices, int n_devices, const RayzSceneDesc* scene, uint32_t transport,
+                          RayzMulti** out);
+int rayz_hip_multi_destroy(RayzMulti* multi);
+/* n_devices, the transport in use and RCCL's version code (0 with peer copies); any pointer may be NULL */
+int rayz_hip_multi_info(const RayzMulti* multi, int* n_devices, uint32_t* transport, int* rccl_version);
+/* `tracer.render()` on all devices of the handle.  stats: counts summed over the devices, kernel_ms = slowest. */
+int rayz_hip_multi_render(RayzMulti* multi, const RayzCameraDesc* camera, const RayzRenderParams* params,
+                          float* rgb_out, RayzRenderStats* stats_or_null);
+int rayz_hip_multi_render_f64(RayzMulti* multi, const RayzCameraDesc* camera, const RayzRenderParams* params,
+                              double* rgb_out, RayzRenderStats* stats_or_null);
+/* Same frame, but each device applies `Image.writePPM`'s per-pixel transform (src/image.zig:35-38) to its rows
+ * BEFORE the gather, so the tiles travel as u8 (4x smaller) and `rgb8_out` (height*width*3 bytes) is what
+ * writePPM would print.  f32 precision only. */
+int rayz_hip_multi_render_u8(RayzMulti* multi, const RayzCameraDesc* camera, const RayzRenderParams* params,
+                             uint8_t* rgb8_out, RayzRenderStats* stats_or_null);
+/* One-shot forms: create, render, destroy (RCCL transport). */
+int rayz_hip_render_multi(const int* devices, int n_devices, const RayzSceneDesc* scene,
+                          const RayzCameraDesc* camera, const RayzRenderParams* params, float* rgb_out,
+                          RayzRenderStats* stats_or_null);
+int rayz_hip_render_multi_f64(const int* devices, int n_devices, const RayzSceneDesc* scene,
+                              const RayzCameraDesc* camera, const RayzRenderParams* params, double* rgb_out,
+                              RayzRenderStats* stats_or_null);
+
 /* The step after the path, `Image.writePPM`'s per-pixel transform (src/image.zig:35-38,
  * src/vec.zig:79-93): sqrt-gamma, clamp to [0,1], truncate x*255 to u8.  Device to device,
  * n_pixels*3 floats in, n_pixels*3 bytes out. */
-int rayz_hip_tonemap_u8(const float* d_rgb, uint8_t* d_rgb8, size_t n_pixels, void* hip_stream);
+int rayz_hip_tonemap_u8(const float* d_rgb, uint8_t* d_rgb8, size_t n_pixels, void* hip_stream); /* default device */
 
 #ifdef __cplusplus
 }

@@ -53,6 +53,8 @@ int64_t rayz_tracer_add_triangle(RayzTracer* t, const double* v0, const double* 
 
 int rayz_tracer_set_u64(RayzTracer* t, int field, uint64_t value);
 int rayz_tracer_set_f64(RayzTracer* t, int field, double value);
+/* devices render() drives (rayz_hip_render_multi: rows dealt to them, one RCCL gather); n = 0: the default device */
+int rayz_tracer_set_devices(RayzTracer* t, const int* devices, int n);
 int rayz_tracer_info(const RayzTracer* t, RayzTracerInfo* out);
 
 /* Tracer.camera after Camera.init, src/camera.zig:18-57 */

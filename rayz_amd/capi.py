@@ -12,7 +12,9 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "librayz_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
+MAX_DEVICES = 64
+GATHER_RCCL, GATHER_PEER_COPY = 0, 1
 
 OK = 0
 ERR_BAD_ARG = -1
@@ -83,7 +85,9 @@ PROTOTYPES = [
     ("rayz_hip_last_error", C.c_char_p, []),
     ("rayz_hip_abi_version", C.c_uint32, []),
     ("rayz_hip_shard_rows", C.c_uint32, [C.POINTER(RenderParams)]),
+    ("rayz_hip_chunk_spp", C.c_uint32, [C.POINTER(RenderParams)]),
     ("rayz_hip_scene_create", C.c_int, [C.POINTER(SceneDesc), C.POINTER(C.c_void_p)]),
+    ("rayz_hip_scene_create_on", C.c_int, [C.c_int, C.POINTER(SceneDesc), C.POINTER(C.c_void_p)]),
     ("rayz_hip_scene_destroy", C.c_int, [C.c_void_p]),
     ("rayz_hip_scene_bvh", C.c_int,
      [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.POINTER(C.c_uint32),
@@ -100,6 +104,22 @@ PROTOTYPES = [
      [C.POINTER(SceneDesc), C.POINTER(CameraDesc), C.POINTER(RenderParams), C.c_void_p,
       C.POINTER(RenderStats)]),
     ("rayz_hip_tonemap_u8", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    ("rayz_hip_multi_create", C.c_int,
+     [C.POINTER(C.c_int), C.c_int, C.POINTER(SceneDesc), C.c_uint32, C.POINTER(C.c_void_p)]),
+    ("rayz_hip_multi_destroy", C.c_int, [C.c_void_p]),
+    ("rayz_hip_multi_info", C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
+    ("rayz_hip_multi_render", C.c_int,
+     [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderParams), C.c_void_p, C.POINTER(RenderStats)]),
+    ("rayz_hip_multi_render_f64", C.c_int,
+     [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderParams), C.c_void_p, C.POINTER(RenderStats)]),
+    ("rayz_hip_multi_render_u8", C.c_int,
+     [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderParams), C.c_void_p, C.POINTER(RenderStats)]),
+    ("rayz_hip_render_multi", C.c_int,
+     [C.POINTER(C.c_int), C.c_int, C.POINTER(SceneDesc), C.POINTER(CameraDesc), C.POINTER(RenderParams), C.c_void_p,
+      C.POINTER(RenderStats)]),
+    ("rayz_hip_render_multi_f64", C.c_int,
+     [C.POINTER(C.c_int), C.c_int, C.POINTER(SceneDesc), C.POINTER(CameraDesc), C.POINTER(RenderParams), C.c_void_p,
+      C.POINTER(RenderStats)]),
 ]
 
 

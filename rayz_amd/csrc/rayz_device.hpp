@@ -48,8 +48,9 @@ template <> struct VecOf<double> { typedef d4 type; typedef d2 pair; };
 
 // ---- device-resident scene (HBM layout) ------------------------------------------
 // Scan streams, one per velocity class, each padded with never-hit records (r² = -inf):
-//   static  v = 0            stat: blocks of G = 8 spheres, SoA inside a block: cx[8] cy[8] cz[8] r²[8]
-//   mov-Y   v = (0, vy, 0)   movy: blocks of 8:                                 cx[8] cy[8] cz[8] r²[8] vy[8]
+//   static  v = 0            stat: blocks of G = group_size<R>() spheres (4 in f32, 2 in f64), SoA inside a block:
+//                                  cx[G] cy[G] cz[G] r²[G]
+//   mov-Y   v = (0, vy, 0)   movy: blocks of G: cx[G] cy[G] cz[G] r²[G] vy[G]
 //                            (what randomBouncing makes)
 //   mov-G   any other v      movg[2i] = {cx, cy, cz, r²}, movg[2i+1] = {vx, vy, vz, 0}
 // The block layout puts the same field of two neighbouring spheres in one aligned SGPR pair, which is what a
@@ -558,8 +559,8 @@ __device__ __forceinline__ void scan_triangles(const DevScene<R>& sc, ScanRay<R>
 // that never reloads runs in the same time), not occupancy, not instruction-level parallelism — but the rate at
 // which VALU instructions can read DIFFERENT scalar registers (≈2.75 cycles each), plus ≈10 cycles per reject
 // branch.  Hence two spheres per packed FMA (ScanGroup::discs) and one branch per 8 tests (scan_class).
-// NR = 2 rays per lane (RAYZ_RAYS=2) halves the scalar loads per test; it is kept as a measurement variant
-// and is not faster.
+// NR = rays per lane; the product instantiates NR = 1 (two rays per lane halve the scalar loads per test and
+// were measured no faster).
 template <class R, int NR>
 __device__ __forceinline__ void scan_begin(ScanRay<R>& ray, V<R> o, V<R> d, V<R> ud, R time) {
     ray.o = o;
@@ -769,7 +770,7 @@ __device__ __forceinline__ void path_refill(PathState<R>& p, const TraceArgs<R>&
 // time, runs its paths one after the other, adds their radiance in sample order, and stores the chunk sum to
 // partial[item]; resolve_kernel adds the chunk sums of a pixel in chunk order.  The summation tree is therefore
 // fixed by (spp, chunk_spp) alone — not by the schedule, the grid size, NR or the number of GPUs.
-template <class R, int NR, bool SYNC> __global__ __launch_bounds__(256, NR == 1 ? 4 : 3) void trace_kernel(const TraceArgs<R> A) {
+template <class R, int NR> __global__ __launch_bounds__(256, NR == 1 ? 4 : 3) void trace_kernel(const TraceArgs<R> A) {
     const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     PathState<R> p[NR];
 #pragma unroll
@@ -791,9 +792,7 @@ template <class R, int NR, bool SYNC> __global__ __launch_bounds__(256, NR == 1 
             path_refill<R>(p[r], A, lane, queue_empty);
             any = any || p[r].alive;
         }
-        if (SYNC) { // measurement variant: workgroup-synchronous bounce iteration (lockstep waves)
-            if (__syncthreads_or(any ? 1 : 0) == 0) break;
-        } else if (__ballot(any) == 0ull) break; // queue drained and every slot idle: the wave is done
+        if (__ballot(any) == 0ull) break; // queue drained and every slot idle: the wave is done
 
         RAYZ_FPROF(0)
         // ---- nearest hit (full EXEC; idle tail slots recompute their last ray, results unused) ----

@@ -1,19 +1,29 @@
 // rayz_hip.hip — the C ABI of include/rayz_hip.h: scene upload, workspace, kernel launches.
 //
-// Replaces the body of `Tracer.render()` (src/renderer.zig:72-101 of jlucier/rayz).  One process
-// drives one GPU; multi-GPU sharding is by interleaved row tiles (params.shard_*), the gather is the
-// caller's (RCCL through torch.distributed in bench.py).
+// Replaces the body of `Tracer.render()` (src/renderer.zig:72-101 of jlucier/rayz).  A scene handle is bound to
+// ONE device (its own context: stream, CU count); a process may drive several devices — one scene per device,
+// rows dealt in interleaved tiles (params.shard_*) — either itself (rayz_hip_multi_*: one host thread, one stream
+// per device, one RCCL gather of the row tiles to the first device) or as one process per GPU with the gather
+// done by the caller (torch.distributed in bench.py).
 #include "../../include/rayz_hip.h"
 #include "rayz_device.hpp"
 #include "bvh_build.hpp"
+
+#include <rccl/rccl.h> // types and prototypes only: the library is opened with dlopen at the first multi-device call
+
+#include <dlfcn.h>
 
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <limits>
+#include <mutex>
+#include <algorithm>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 using namespace rayz_dev;
@@ -21,9 +31,6 @@ using namespace rayz_dev;
 namespace {
 
 thread_local char g_err[512] = "";
-int g_device = -1;
-hipStream_t g_stream = nullptr;
-int g_num_cu = 0;
 
 int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -32,6 +39,44 @@ int fail(int code, const char* fmt, ...) {
     va_end(ap);
     return code;
 }
+
+// No exception crosses the C ABI: every extern "C" body that can allocate runs inside guarded().
+template <class F> int guarded(F&& f) noexcept {
+    try {
+        return f();
+    } catch (const std::bad_alloc&) {
+        return fail(RAYZ_ERR_OOM, "host allocation failed");
+    } catch (const std::exception& e) {
+        return fail(RAYZ_ERR_HIP, "unexpected exception: %s", e.what());
+    } catch (...) {
+        return fail(RAYZ_ERR_HIP, "unexpected exception");
+    }
+}
+
+// One context per HIP device ordinal, created by rayz_hip_init(device) (or lazily by the *_on / multi entries).
+struct DeviceCtx {
+    bool ok = false;
+    hipStream_t stream = nullptr;
+    int num_cu = 0;
+};
+DeviceCtx g_ctx[RAYZ_MAX_DEVICES];
+int g_default = -1; // device of the last successful rayz_hip_init: what entry points without a device argument use
+std::mutex g_mu;    // guards g_ctx / g_default
+
+// HIP's current device is per host thread: every entry point that touches a device selects it and restores the
+// caller's on return (the host may be torch, with its own idea of the current device).
+struct DeviceScope {
+    int prev = -1, dev;
+    explicit DeviceScope(int d) : dev(d) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) (void)hipSetDevice(dev);
+    }
+    ~DeviceScope() {
+        if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
+    }
+    DeviceScope(const DeviceScope&) = delete;
+    DeviceScope& operator=(const DeviceScope&) = delete;
+};
 
 #define HIP_TRY(expr)                                                                                       \
     do {                                                                                                    \
@@ -61,8 +106,8 @@ template <> struct Bits<double> {
 // Device copy of the scene in one precision: scan streams + pool-indexed shading tables.
 template <class R> struct SceneBuffers {
     typedef typename VecOf<R>::type r4;
-    R* stat = nullptr;  // blocks of 8: cx[8] cy[8] cz[8] r²[8]
-    R* movy = nullptr;  // blocks of 8: cx[8] cy[8] cz[8] r²[8] vy[8]
+    R* stat = nullptr;  // blocks of G = group_size<R>() spheres: cx[G] cy[G] cz[G] r²[G]
+    R* movy = nullptr;  // blocks of G: cx[G] cy[G] cz[G] r²[G] vy[G]
     r4* movg = nullptr;
     r4* sph_pool = nullptr;
     r4* mat = nullptr;
@@ -114,6 +159,7 @@ uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
 } // namespace
 
 struct RayzScene {
+    int device = -1; // HIP ordinal this scene's buffers live on; bound at creation (_on) or at the first render
     std::vector<RayzSphere> spheres;
     std::vector<RayzMaterial> materials;
     std::vector<RayzTexture> textures;
@@ -158,9 +204,8 @@ void classify(RayzScene* s) {
 uint32_t scan_len(size_t n, uint32_t group) { return round_up((uint32_t)n, 2 * group); }
 uint32_t stream_len(size_t n, uint32_t group) { return scan_len(n, group) + 2 * group; }
 
-int upload_narrow(RayzScene* s) {
+int upload_narrow_body(RayzScene* s) {
     NarrowBuffers& nb = s->narrow;
-    if (nb.ready) return RAYZ_OK;
     classify(s);
     // slot numbering is shared by both precisions: pad to the larger (f32) group size
     nb.ns_pad = scan_len(s->cls[0].size(), kStaticGroup);
@@ -184,9 +229,16 @@ int upload_narrow(RayzScene* s) {
     return RAYZ_OK;
 }
 
-template <class R> int upload(RayzScene* s, SceneBuffers<R>& b) {
+// A failed upload leaves nothing behind: the partly filled buffer set is released, so a retry starts clean.
+int upload_narrow(RayzScene* s) {
+    if (s->narrow.ready) return RAYZ_OK;
+    const int rc = upload_narrow_body(s);
+    if (rc != RAYZ_OK) s->narrow.release();
+    return rc;
+}
+
+template <class R> int upload_body(RayzScene* s, SceneBuffers<R>& b) {
     typedef typename VecOf<R>::type r4;
-    if (b.ready) return RAYZ_OK;
     int rc = upload_narrow(s);
     if (rc != RAYZ_OK) return rc;
     const R ninf = -std::numeric_limits<R>::infinity();
@@ -254,6 +306,13 @@ template <class R> int upload(RayzScene* s, SceneBuffers<R>& b) {
     return RAYZ_OK;
 }
 
+template <class R> int upload(RayzScene* s, SceneBuffers<R>& b) {
+    if (b.ready) return RAYZ_OK;
+    const int rc = upload_body<R>(s, b);
+    if (rc != RAYZ_OK) b.release();
+    return rc;
+}
+
 void ensure_bvh(RayzScene* s) {
     if (!s->bvh_built) {
         s->bvh = rayz_bvh::build(s->spheres, s->triangles); // replaces initHittables + bvh.build, src/renderer.zig:76-78
@@ -261,7 +320,7 @@ void ensure_bvh(RayzScene* s) {
     }
 }
 
-template <class R> int upload_bvh(RayzScene* s, SceneBuffers<R>& b) {
+template <class R> int upload_bvh_body(RayzScene* s, SceneBuffers<R>& b) {
     typedef typename VecOf<R>::type r4;
     ensure_bvh(s);
     const rayz_bvh::FlatBvh& t = s->bvh;
@@ -336,6 +395,62 @@ template <class R> int upload_bvh(RayzScene* s, SceneBuffers<R>& b) {
     return RAYZ_OK;
 }
 
+template <class R> int upload_bvh(RayzScene* s, SceneBuffers<R>& b) {
+    if (b.bvh_ready && s->narrow.bvh_ready) return RAYZ_OK;
+    const int rc = upload_bvh_body<R>(s, b);
+    if (rc != RAYZ_OK) { // drop the partly built BVH buffers (the scan streams stay valid)
+        (void)hipFree(b.bvh_nodes);
+        (void)hipFree(b.bvh_leaf);
+        b.bvh_nodes = b.bvh_leaf = nullptr;
+        b.bvh_ready = false;
+        if (!s->narrow.bvh_ready) {
+            (void)hipFree(s->narrow.bvh_sph64);
+            s->narrow.bvh_sph64 = nullptr;
+        }
+    }
+    return rc;
+}
+
+// Nesting depth of every texture (solid = 1, checker = 1 + deeper child); 0 marks a cycle.  The device walks a
+// checker chain with a bounded loop (kMaxTextureDepth lookups) where the reference recurses without a limit
+// (src/material.zig:36-37): a pool the loop cannot resolve is refused here instead of rendering black.
+int texture_depths(const RayzSceneDesc* d, std::vector<uint32_t>& depth) {
+    const uint32_t n = d->n_textures;
+    depth.assign(n, 0u);
+    std::vector<uint8_t> state(n, 0); // 0 unvisited, 1 on the stack, 2 done
+    std::vector<uint32_t> stack;
+    for (uint32_t root = 0; root < n; ++root) {
+        if (state[root]) continue;
+        stack.push_back(root);
+        while (!stack.empty()) {
+            const uint32_t i = stack.back();
+            const RayzTexture& t = d->textures[i];
+            if (t.kind == RAYZ_TEX_SOLID) {
+                depth[i] = 1, state[i] = 2;
+                stack.pop_back();
+                continue;
+            }
+            if (state[i] == 0) {
+                state[i] = 1;
+                bool pushed = false;
+                for (uint32_t c : {t.even, t.odd}) {
+                    if (state[c] == 1) return fail(RAYZ_ERR_BAD_ARG, "texture %u: checker chain contains a cycle (through %u)", i, c);
+                    if (state[c] == 0) stack.push_back(c), pushed = true;
+                }
+                if (pushed) continue;
+            }
+            // both children done (or were done already)
+            if (state[t.even] != 2 || state[t.odd] != 2) { // a child is still on the stack below us: a cycle
+                return fail(RAYZ_ERR_BAD_ARG, "texture %u: checker chain contains a cycle", i);
+            }
+            depth[i] = 1 + (depth[t.even] > depth[t.odd] ? depth[t.even] : depth[t.odd]);
+            state[i] = 2;
+            stack.pop_back();
+        }
+    }
+    return RAYZ_OK;
+}
+
 int validate_scene(const RayzSceneDesc* d) {
     if (!d) return fail(RAYZ_ERR_BAD_ARG, "scene is null");
     if ((d->n_spheres && !d->spheres) || (d->n_materials && !d->materials) || (d->n_textures && !d->textures) ||
@@ -349,6 +464,15 @@ int validate_scene(const RayzSceneDesc* d) {
         if (t.kind > RAYZ_TEX_SOLID) return fail(RAYZ_ERR_BAD_ARG, "texture %u: bad kind %u", i, t.kind);
         if (t.kind == RAYZ_TEX_CHECKER && (t.even >= d->n_textures || t.odd >= d->n_textures))
             return fail(RAYZ_ERR_BAD_ARG, "texture %u: checker handle out of range", i);
+    }
+    {
+        std::vector<uint32_t> depth;
+        const int rc = texture_depths(d, depth);
+        if (rc != RAYZ_OK) return rc;
+        for (uint32_t i = 0; i < d->n_textures; ++i)
+            if (depth[i] > (uint32_t)kMaxTextureDepth)
+                return fail(RAYZ_ERR_BAD_ARG, "texture %u: checker nesting depth %u exceeds the device limit %d", i, depth[i],
+                            kMaxTextureDepth);
     }
     for (uint32_t i = 0; i < d->n_materials; ++i) {
         const RayzMaterial& m = d->materials[i];
@@ -388,15 +512,50 @@ template <class R> void fill_camera(const RayzCameraDesc* c, DevCamera<R>& o) {
     o._pad = 0;
 }
 
+// ---- device contexts -----------------------------------------------------------------------------------
+int ensure_ctx(int device) { // creates the context of `device` if needed; g_mu held by the caller
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(RAYZ_ERR_NO_DEVICE, "no HIP device: %s", hipGetErrorString(e));
+    if (device < 0 || device >= n || device >= RAYZ_MAX_DEVICES)
+        return fail(RAYZ_ERR_BAD_ARG, "device %d out of range [0,%d)", device, n < RAYZ_MAX_DEVICES ? n : RAYZ_MAX_DEVICES);
+    DeviceCtx& c = g_ctx[device];
+    if (c.ok) return RAYZ_OK;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(RAYZ_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 code only", device, prop.gcnArchName);
+    DeviceScope scope(device);
+    HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    c.num_cu = prop.multiProcessorCount;
+    c.ok = true;
+    return RAYZ_OK;
+}
+
+// The context a scene renders on.  A scene created without a device is bound to the default device here.
+int scene_ctx(RayzScene* s, DeviceCtx** out) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (s->device < 0) {
+        if (g_default < 0) return fail(RAYZ_ERR_NO_DEVICE, "rayz_hip_init has not succeeded");
+        s->device = g_default;
+    }
+    if (!g_ctx[s->device].ok) return fail(RAYZ_ERR_NO_DEVICE, "device %d is not initialised (rayz_hip_init / shutdown order)", s->device);
+    *out = &g_ctx[s->device];
+    return RAYZ_OK;
+}
+
+// Launches one render of `p`'s shard on the scene's device.  The caller has selected that device (DeviceScope).
+// A scene supports ONE render in flight: a second call first waits for the previous one (its workspace and
+// counters are reused).
 template <class R>
-int render_impl(RayzScene* s, SceneBuffers<R>& b, const RayzCameraDesc* cam, const RayzRenderParams* p, R* d_out,
-                hipStream_t stream) {
+int render_impl(RayzScene* s, const DeviceCtx& ctx, SceneBuffers<R>& b, const RayzCameraDesc* cam, const RayzRenderParams* p,
+                R* d_out, hipStream_t stream) {
     typedef typename VecOf<R>::type r4;
-    if (g_device < 0) return fail(RAYZ_ERR_NO_DEVICE, "rayz_hip_init has not succeeded");
     const bool use_bvh = p->traversal == RAYZ_TRAVERSAL_BVH ||
                          (p->traversal == RAYZ_TRAVERSAL_AUTO && s->spheres.size() + s->triangles.size() > RAYZ_AUTO_BVH_MIN);
     if (s->spheres.size() + s->triangles.size() >= (1u << 27))
         return fail(RAYZ_ERR_BAD_ARG, "too many hittables for the device layout");
+    if (s->last_stream && s->last_stream != stream) HIP_TRY(hipStreamSynchronize(s->last_stream)); // previous render done
     int rc = upload<R>(s, b);
     if (rc != RAYZ_OK) return rc;
     if (use_bvh) {
@@ -408,20 +567,20 @@ int render_impl(RayzScene* s, SceneBuffers<R>& b, const RayzCameraDesc* cam, con
 
     const uint32_t rows = rayz_hip_shard_rows(p);
     const uint64_t shard_pixels64 = (uint64_t)rows * p->width;
-    const uint32_t chunk = p->chunk_spp ? p->chunk_spp : 16u;
+    const uint32_t chunk = rayz_hip_chunk_spp(p);
     const uint32_t chunks_per_px = (p->samples_per_px + chunk - 1) / chunk;
     const uint64_t items64 = shard_pixels64 * chunks_per_px;
     if (shard_pixels64 >= (1ull << 31) || items64 >= (1ull << 32) - (1ull << 26))
         return fail(RAYZ_ERR_BAD_ARG, "too many work items (%llu): raise chunk_spp", (unsigned long long)items64);
     s->last = RayzRenderStats{};
     s->last.primary_rays = shard_pixels64 * p->samples_per_px;
-    s->last_stream = stream;
     s->last_bvh = use_bvh;
     if (items64 == 0) {
         s->rendered = false;
         return RAYZ_OK;
     }
     if (!d_out) return fail(RAYZ_ERR_BAD_ARG, "output pointer is null");
+    s->last_stream = stream;
     if (p->max_bounces == 0) { // bounceRay(ray, 0) is black, src/renderer.zig:104-105
         HIP_TRY(hipMemsetAsync(d_out, 0, shard_pixels64 * 3 * sizeof(R), stream));
         s->rendered = false;
@@ -486,30 +645,19 @@ int render_impl(RayzScene* s, SceneBuffers<R>& b, const RayzCameraDesc* cam, con
         A.bvh_keep = (ka & 0xffu) | ((ks & 0xffu) << 8);
     }
 
-    const char* feed = std::getenv("RAYZ_FEED");
-    const bool use_lds = false; // the LDS-tiled measurement variant was retired with the block layout
-    // rays per lane of the flat-list kernel: 1.  RAYZ_RAYS=2 (register tiling: every fetched record tested against
-    // two rays per lane) and RAYZ_FEED=sync (a workgroup barrier per bounce iteration) are measurement variants —
-    // neither is faster: the scan is bound by VALU issue cycles, not by the sphere feed
-    int nr = 1;
-    if (const char* e = std::getenv("RAYZ_RAYS")) nr = std::atoi(e) == 2 ? 2 : 1;
-    const bool sync = !use_bvh && feed && std::strcmp(feed, "sync") == 0;
     const int block = 256;
-    void (*lin)(const TraceArgs<R>) = nr == 2 ? (sync ? trace_kernel<R, 2, true> : trace_kernel<R, 2, false>)
-                                               : (sync ? trace_kernel<R, 1, true> : trace_kernel<R, 1, false>);
     int blocks_per_cu = 0;
-    if (use_bvh) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, trace_kernel_bvh<R>, 256, 0));
-    else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, lin, 256, 0));
+    if (use_bvh) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, trace_kernel_bvh<R>, block, 0));
+    else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, trace_kernel<R, 1>, block, 0));
     if (blocks_per_cu < 1) blocks_per_cu = 1;
-    uint64_t grid = (uint64_t)g_num_cu * blocks_per_cu;
-    const uint64_t per_block = (uint64_t)block * ((use_bvh || use_lds) ? 1 : nr);
-    const uint64_t want = (items64 + per_block - 1) / per_block;
+    uint64_t grid = (uint64_t)ctx.num_cu * blocks_per_cu;
+    const uint64_t want = (items64 + block - 1) / block;
     if (grid > want) grid = want;
 
     HIP_TRY(hipMemsetAsync(s->counters, 0, 16 * sizeof(unsigned long long), stream));
     HIP_TRY(hipEventRecord(s->ev0, stream));
-    if (use_bvh) hipLaunchKernelGGL(trace_kernel_bvh<R>, dim3((uint32_t)grid), dim3(256), 0, stream, A);
-    else hipLaunchKernelGGL(lin, dim3((uint32_t)grid), dim3(256), 0, stream, A);
+    if (use_bvh) hipLaunchKernelGGL(trace_kernel_bvh<R>, dim3((uint32_t)grid), dim3(block), 0, stream, A);
+    else hipLaunchKernelGGL((trace_kernel<R, 1>), dim3((uint32_t)grid), dim3(block), 0, stream, A);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev1, stream));
     hipLaunchKernelGGL(resolve_kernel<R>, dim3((A.shard_pixels + 255) / 256), dim3(256), 0, stream,
@@ -530,87 +678,20 @@ int check_render_args(RayzScene* s, const RayzCameraDesc* cam, const RayzRenderP
 }
 
 template <class R>
-int render_oneshot(const RayzSceneDesc* scene, const RayzCameraDesc* cam, const RayzRenderParams* p, R* out,
-                   RayzRenderStats* stats, uint32_t precision) {
-    if (!out) return fail(RAYZ_ERR_BAD_ARG, "output pointer is null");
-    int rc = validate_params(p);
+int render_device(RayzScene* s, const RayzCameraDesc* cam, const RayzRenderParams* p, R* d_out, void* stream, uint32_t precision) {
+    int rc = check_render_args(s, cam, p, precision);
     if (rc != RAYZ_OK) return rc;
-    if (g_device < 0) {
-        rc = rayz_hip_init(0);
-        if (rc != RAYZ_OK) return rc;
-    }
-    RayzScene* s = nullptr;
-    rc = rayz_hip_scene_create(scene, &s);
+    DeviceCtx* ctx = nullptr;
+    rc = scene_ctx(s, &ctx);
     if (rc != RAYZ_OK) return rc;
-    const size_t n = (size_t)rayz_hip_shard_rows(p) * p->width * 3;
-    R* d_out = nullptr;
-    hipError_t e = hipMalloc((void**)&d_out, n ? n * sizeof(R) : 16);
-    if (e != hipSuccess) {
-        rayz_hip_scene_destroy(s);
-        return fail(RAYZ_ERR_OOM, "hipMalloc(output): %s", hipGetErrorString(e));
-    }
-    rc = check_render_args(s, cam, p, precision);
-    if (rc == RAYZ_OK) {
-        if (precision == RAYZ_PRECISION_F32) rc = render_impl<float>(s, s->f32, cam, p, (float*)d_out, g_stream);
-        else rc = render_impl<double>(s, s->f64, cam, p, (double*)d_out, g_stream);
-    }
-    if (rc == RAYZ_OK) rc = rayz_hip_scene_sync(s, stats);
-    if (rc == RAYZ_OK && n) {
-        e = hipMemcpy(out, d_out, n * sizeof(R), hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rc = fail(RAYZ_ERR_HIP, "hipMemcpy(output): %s", hipGetErrorString(e));
-    }
-    (void)hipFree(d_out);
-    rayz_hip_scene_destroy(s);
-    return rc;
+    DeviceScope scope(s->device);
+    SceneBuffers<R>* b;
+    if constexpr (sizeof(R) == 4) b = &s->f32;
+    else b = &s->f64;
+    return render_impl<R>(s, *ctx, *b, cam, p, d_out, stream ? (hipStream_t)stream : ctx->stream);
 }
 
-} // namespace
-
-extern "C" {
-
-uint32_t rayz_hip_abi_version(void) { return RAYZ_HIP_ABI_VERSION; }
-const char* rayz_hip_last_error(void) { return g_err; }
-
-int rayz_hip_init(int device) {
-    if (g_device == device && g_stream) return RAYZ_OK;
-    int n = 0;
-    hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess || n <= 0) return fail(RAYZ_ERR_NO_DEVICE, "no HIP device: %s", hipGetErrorString(e));
-    if (device < 0 || device >= n) return fail(RAYZ_ERR_BAD_ARG, "device %d out of range [0,%d)", device, n);
-    HIP_TRY(hipSetDevice(device));
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, device));
-    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-        return fail(RAYZ_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 code only", device, prop.gcnArchName);
-    if (g_stream) {
-        (void)hipStreamDestroy(g_stream);
-        g_stream = nullptr;
-    }
-    HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
-    g_num_cu = prop.multiProcessorCount;
-    g_device = device;
-    return RAYZ_OK;
-}
-
-void rayz_hip_shutdown(void) {
-    if (g_stream) (void)hipStreamDestroy(g_stream);
-    g_stream = nullptr;
-    g_device = -1;
-}
-
-uint32_t rayz_hip_shard_rows(const RayzRenderParams* p) {
-    if (!p) return 0;
-    const uint32_t tr = p->tile_rows ? p->tile_rows : 8u, sc = p->shard_count ? p->shard_count : 1u;
-    if (p->shard_index >= sc) return 0;
-    uint32_t n = 0;
-    for (uint32_t t = p->shard_index; (uint64_t)t * tr < p->height; t += sc) {
-        const uint32_t r0 = t * tr;
-        n += (p->height - r0 < tr) ? p->height - r0 : tr;
-    }
-    return n;
-}
-
-int rayz_hip_scene_create(const RayzSceneDesc* scene, RayzScene** out) {
+int scene_new(const RayzSceneDesc* scene, int device, RayzScene** out) {
     if (!out) return fail(RAYZ_ERR_BAD_ARG, "out handle pointer is null");
     *out = nullptr;
     int rc = validate_scene(scene);
@@ -626,42 +707,19 @@ int rayz_hip_scene_create(const RayzSceneDesc* scene, RayzScene** out) {
         delete s;
         return fail(RAYZ_ERR_OOM, "host allocation failed");
     }
+    s->device = device;
     *out = s;
     return RAYZ_OK;
 }
 
-int rayz_hip_scene_destroy(RayzScene* s) {
-    if (!s) return RAYZ_OK;
-    if (s->last_stream || g_stream) (void)hipStreamSynchronize(s->last_stream ? s->last_stream : g_stream);
-    s->f32.release();
-    s->f64.release();
-    s->narrow.release();
-    (void)hipFree(s->partial);
-    (void)hipFree(s->counters);
-    if (s->ev0) (void)hipEventDestroy(s->ev0);
-    if (s->ev1) (void)hipEventDestroy(s->ev1);
-    delete s;
-    return RAYZ_OK;
-}
-
-int rayz_hip_render_device(RayzScene* s, const RayzCameraDesc* cam, const RayzRenderParams* p, float* d_out,
-                           void* stream) {
-    int rc = check_render_args(s, cam, p, RAYZ_PRECISION_F32);
-    if (rc != RAYZ_OK) return rc;
-    return render_impl<float>(s, s->f32, cam, p, d_out, stream ? (hipStream_t)stream : g_stream);
-}
-
-int rayz_hip_render_device_f64(RayzScene* s, const RayzCameraDesc* cam, const RayzRenderParams* p, double* d_out,
-                               void* stream) {
-    int rc = check_render_args(s, cam, p, RAYZ_PRECISION_F64);
-    if (rc != RAYZ_OK) return rc;
-    return render_impl<double>(s, s->f64, cam, p, d_out, stream ? (hipStream_t)stream : g_stream);
-}
-
-int rayz_hip_scene_sync(RayzScene* s, RayzRenderStats* stats) {
+int scene_sync(RayzScene* s, RayzRenderStats* stats) {
     if (!s) return fail(RAYZ_ERR_STATE, "scene handle is null");
-    if (g_device < 0) return fail(RAYZ_ERR_NO_DEVICE, "rayz_hip_init has not succeeded");
-    HIP_TRY(hipStreamSynchronize(s->last_stream ? s->last_stream : g_stream));
+    if (s->device < 0) { // never rendered: nothing to wait for
+        if (stats) *stats = s->last;
+        return RAYZ_OK;
+    }
+    DeviceScope scope(s->device);
+    if (s->last_stream) HIP_TRY(hipStreamSynchronize(s->last_stream));
     if (s->rendered) {
         unsigned long long c[16] = {};
         HIP_TRY(hipMemcpy(c, s->counters, sizeof(c), hipMemcpyDeviceToHost));
@@ -695,47 +753,546 @@ int rayz_hip_scene_sync(RayzScene* s, RayzRenderStats* stats) {
     return RAYZ_OK;
 }
 
+int scene_free(RayzScene* s) {
+    if (!s) return RAYZ_OK;
+    if (s->device >= 0) {
+        DeviceScope scope(s->device);
+        if (s->last_stream) (void)hipStreamSynchronize(s->last_stream);
+        s->f32.release();
+        s->f64.release();
+        s->narrow.release();
+        (void)hipFree(s->partial);
+        (void)hipFree(s->counters);
+        if (s->ev0) (void)hipEventDestroy(s->ev0);
+        if (s->ev1) (void)hipEventDestroy(s->ev1);
+    }
+    delete s;
+    return RAYZ_OK;
+}
+
+template <class R>
+int render_oneshot(const RayzSceneDesc* scene, const RayzCameraDesc* cam, const RayzRenderParams* p, R* out,
+                   RayzRenderStats* stats, uint32_t precision) {
+    if (!out) return fail(RAYZ_ERR_BAD_ARG, "output pointer is null");
+    int rc = validate_params(p);
+    if (rc != RAYZ_OK) return rc;
+    int device;
+    {
+        std::unique_lock<std::mutex> lock(g_mu);
+        device = g_default;
+    }
+    if (device < 0) {
+        rc = rayz_hip_init(0);
+        if (rc != RAYZ_OK) return rc;
+        device = 0;
+    }
+    RayzScene* s = nullptr;
+    rc = scene_new(scene, device, &s);
+    if (rc != RAYZ_OK) return rc;
+    DeviceScope scope(device);
+    const size_t n = (size_t)rayz_hip_shard_rows(p) * p->width * 3;
+    R* d_out = nullptr;
+    hipError_t e = hipMalloc((void**)&d_out, n ? n * sizeof(R) : 16);
+    if (e != hipSuccess) {
+        scene_free(s);
+        return fail(RAYZ_ERR_OOM, "hipMalloc(output): %s", hipGetErrorString(e));
+    }
+    rc = render_device<R>(s, cam, p, d_out, nullptr, precision);
+    if (rc == RAYZ_OK) rc = scene_sync(s, stats);
+    if (rc == RAYZ_OK && n) {
+        e = hipMemcpy(out, d_out, n * sizeof(R), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(RAYZ_ERR_HIP, "hipMemcpy(output): %s", hipGetErrorString(e));
+    }
+    (void)hipFree(d_out);
+    scene_free(s);
+    return rc;
+}
+
+// ---- RCCL, opened at run time ------------------------------------------------------------------------------
+// The single-device entry points must not depend on RCCL being loadable, and a host that already carries an RCCL
+// (torch ships one with the same soname) must not get a second copy: dlopen by soname reuses what is mapped.
+struct Rccl {
+    void* handle = nullptr;
+    bool tried = false;
+    decltype(&ncclGetVersion) GetVersion = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGather) Gather = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+Rccl g_rccl;
+
+int rccl_load() { // g_mu held
+    Rccl& r = g_rccl;
+    if (r.handle) return RAYZ_OK;
+    if (r.tried) return fail(RAYZ_ERR_STATE, "RCCL is not available (librccl.so.1 could not be loaded)");
+    r.tried = true;
+    const char* names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+    void* h = nullptr;
+    for (const char* n : names)
+        if ((h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+    if (!h) return fail(RAYZ_ERR_STATE, "RCCL is not available: %s", dlerror());
+    bool ok = true;
+    auto sym = [&](const char* name) {
+        void* p = dlsym(h, name);
+        if (!p) ok = false;
+        return p;
+    };
+    r.GetVersion = (decltype(r.GetVersion))sym("ncclGetVersion");
+    r.CommInitAll = (decltype(r.CommInitAll))sym("ncclCommInitAll");
+    r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+    r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+    r.Gather = (decltype(r.Gather))sym("ncclGather");
+    r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+    if (!ok) {
+        dlclose(h);
+        return fail(RAYZ_ERR_STATE, "RCCL is not available: librccl lacks a required symbol");
+    }
+    r.handle = h;
+    return RAYZ_OK;
+}
+
+#define NCCL_TRY(expr)                                                                                      \
+    do {                                                                                                    \
+        ncclResult_t r_ = (expr);                                                                           \
+        if (r_ != ncclSuccess)                                                                              \
+            return fail(RAYZ_ERR_HIP, "%s: %s (%s:%d)", #expr, g_rccl.GetErrorString(r_), __FILE__, __LINE__); \
+    } while (0)
+
+// Interleaved row tiles back into the frame: gathered[rank][local row][w*3] -> frame[row][w*3] (on the root device).
+template <class T>
+__global__ __launch_bounds__(256) void unshard_kernel(const T* __restrict__ gathered, T* __restrict__ frame, uint32_t height,
+                                                      uint32_t row_elems, uint32_t tile_rows, uint32_t n_ranks,
+                                                      uint32_t max_rows) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)height * row_elems) return;
+    const uint32_t y = (uint32_t)(i / row_elems), x = (uint32_t)(i - (size_t)y * row_elems);
+    const uint32_t tile = y / tile_rows, rank = tile % n_ranks, local = (tile / n_ranks) * tile_rows + (y - tile * tile_rows);
+    frame[i] = gathered[((size_t)rank * max_rows + local) * row_elems + x];
+}
+
+} // namespace
+
+// One scene per device + the buffers of the gather; everything is driven by the calling host thread.
+struct RayzMulti {
+    std::vector<int> devices;
+    std::vector<RayzScene*> scenes;
+    std::vector<ncclComm_t> comms; // RAYZ_GATHER_RCCL
+    std::vector<void*> tile;       // per device: this device's rows, grow-only
+    std::vector<void*> tile8;      // per device: the same rows tone-mapped to u8 (render_u8 only)
+    std::vector<size_t> tile_have, tile8_have;
+    std::vector<hipEvent_t> done;  // per device: tile ready (peer-copy transport)
+    void* gathered = nullptr; // root: [n][max_rows][row bytes]
+    void* frame = nullptr;    // root: the assembled frame
+    size_t gathered_bytes = 0, frame_bytes = 0;
+    uint32_t transport = RAYZ_GATHER_RCCL;
+    int rccl_version = 0;
+};
+
+namespace {
+
+int multi_free(RayzMulti* m) {
+    if (!m) return RAYZ_OK;
+    for (size_t i = 0; i < m->devices.size(); ++i) {
+        if (i < m->scenes.size()) scene_free(m->scenes[i]); // waits for the device's last render
+        DeviceScope scope(m->devices[i]);
+        if (i < m->comms.size() && m->comms[i]) (void)g_rccl.CommDestroy(m->comms[i]);
+        if (i < m->tile.size()) (void)hipFree(m->tile[i]);
+        if (i < m->tile8.size()) (void)hipFree(m->tile8[i]);
+        if (i < m->done.size() && m->done[i]) (void)hipEventDestroy(m->done[i]);
+    }
+    if (!m->devices.empty()) {
+        DeviceScope scope(m->devices[0]);
+        (void)hipFree(m->gathered);
+        (void)hipFree(m->frame);
+    }
+    delete m;
+    return RAYZ_OK;
+}
+
+int check_device_list(const int* devices, int n) {
+    if (!devices) return fail(RAYZ_ERR_BAD_ARG, "device list is null");
+    if (n < 1 || n > RAYZ_MAX_DEVICES) return fail(RAYZ_ERR_BAD_ARG, "n_devices %d out of range [1,%d]", n, RAYZ_MAX_DEVICES);
+    for (int i = 0; i < n; ++i) {
+        if (devices[i] < 0 || devices[i] >= RAYZ_MAX_DEVICES) return fail(RAYZ_ERR_BAD_ARG, "device %d out of range", devices[i]);
+        for (int j = 0; j < i; ++j)
+            if (devices[j] == devices[i]) return fail(RAYZ_ERR_BAD_ARG, "device %d is listed twice", devices[i]);
+    }
+    return RAYZ_OK;
+}
+
+int grow(void** buf, size_t* have, size_t need) {
+    if (need <= *have) return RAYZ_OK;
+    (void)hipFree(*buf);
+    *buf = nullptr;
+    *have = 0;
+    HIP_TRY(hipMalloc(buf, need));
+    *have = need;
+    return RAYZ_OK;
+}
+
+// T = element type of the frame that crosses the ABI (float, double; uint8_t for the tone-mapped form, rendered in f32).
+template <class T>
+int multi_render(RayzMulti* m, const RayzCameraDesc* cam, const RayzRenderParams* p, T* out, RayzRenderStats* stats) {
+    typedef typename std::conditional<sizeof(T) == 8, double, float>::type R;
+    constexpr bool to_u8 = sizeof(T) == 1;
+    if (!m) return fail(RAYZ_ERR_STATE, "multi handle is null");
+    if (!cam) return fail(RAYZ_ERR_BAD_ARG, "camera is null");
+    if (!out) return fail(RAYZ_ERR_BAD_ARG, "output pointer is null");
+    int rc = validate_params(p);
+    if (rc != RAYZ_OK) return rc;
+    if (p->precision != (sizeof(R) == 8 ? RAYZ_PRECISION_F64 : RAYZ_PRECISION_F32))
+        return fail(RAYZ_ERR_BAD_ARG, "params.precision %u does not match this entry point", p->precision);
+    if (p->shard_index != 0 || p->shard_count > 1)
+        return fail(RAYZ_ERR_BAD_ARG, "the multi-device entry shards the frame itself: shard_index / shard_count must be 0");
+    const uint32_t n = (uint32_t)m->devices.size();
+    RayzRenderParams q = *p;
+    q.chunk_spp = rayz_hip_chunk_spp(p); // resolved on the WHOLE frame: the image must not depend on the device count
+    q.tile_rows = p->tile_rows ? p->tile_rows : 1u; // pure row interleave balances best
+    q.shard_count = n;
+    uint32_t max_rows = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        q.shard_index = i;
+        const uint32_t r = rayz_hip_shard_rows(&q);
+        max_rows = r > max_rows ? r : max_rows;
+    }
+    const size_t row_elems = (size_t)p->width * 3;
+    const size_t tile_bytes = (size_t)max_rows * row_elems * sizeof(R), tile8_bytes = (size_t)max_rows * row_elems;
+    const size_t send_bytes = to_u8 ? tile8_bytes : tile_bytes;
+    const size_t frame_bytes = (size_t)p->height * row_elems * sizeof(T);
+    if ((size_t)p->height * row_elems >= (1ull << 32)) return fail(RAYZ_ERR_BAD_ARG, "frame too large");
+
+    // 1. every device traces its rows (asynchronous: the launches of all devices overlap)
+    std::vector<DeviceCtx*> ctx(n, nullptr);
+    for (uint32_t i = 0; i < n; ++i) {
+        rc = scene_ctx(m->scenes[i], &ctx[i]);
+        if (rc != RAYZ_OK) return rc;
+        DeviceScope scope(m->devices[i]);
+        HIP_TRY(hipStreamSynchronize(ctx[i]->stream)); // the previous frame's gather has left the tiles
+        rc = grow(&m->tile[i], &m->tile_have[i], tile_bytes ? tile_bytes : 16);
+        if (rc == RAYZ_OK && to_u8) rc = grow(&m->tile8[i], &m->tile8_have[i], tile8_bytes ? tile8_bytes : 16);
+        if (rc != RAYZ_OK) return rc;
+    }
+    {
+        DeviceScope scope(m->devices[0]);
+        rc = grow(&m->gathered, &m->gathered_bytes, (size_t)n * send_bytes ? (size_t)n * send_bytes : 16);
+        if (rc == RAYZ_OK) rc = grow(&m->frame, &m->frame_bytes, frame_bytes);
+        if (rc != RAYZ_OK) return rc;
+    }
+    for (uint32_t i = 0; i < n; ++i) {
+        DeviceScope scope(m->devices[i]);
+        q.shard_index = i;
+        SceneBuffers<R>* b;
+        if constexpr (sizeof(R) == 4) b = &m->scenes[i]->f32;
+        else b = &m->scenes[i]->f64;
+        rc = render_impl<R>(m->scenes[i], *ctx[i], *b, cam, &q, (R*)m->tile[i], ctx[i]->stream);
+        if (rc != RAYZ_OK) return rc;
+        if constexpr (to_u8) { // writePPM's transform before the gather: the tiles travel as u8, 4x smaller (src/image.zig:35-38)
+            const size_t ne = (size_t)rayz_hip_shard_rows(&q) * row_elems;
+            if (ne) {
+                hipLaunchKernelGGL(tonemap_kernel, dim3((uint32_t)((ne + 255) / 256)), dim3(256), 0, ctx[i]->stream,
+                                   (const float*)m->tile[i], (uint8_t*)m->tile8[i], ne);
+                HIP_TRY(hipGetLastError());
+            }
+        }
+    }
+    // 2. one gather of the row tiles to the first device
+    auto src = [&](uint32_t i) { return to_u8 ? m->tile8[i] : m->tile[i]; };
+    if (m->transport == RAYZ_GATHER_RCCL) {
+        NCCL_TRY(g_rccl.GroupStart());
+        for (uint32_t i = 0; i < n; ++i) {
+            ncclResult_t r = g_rccl.Gather(src(i), m->gathered, send_bytes, ncclUint8, 0, m->comms[i], ctx[i]->stream);
+            if (r != ncclSuccess) {
+                (void)g_rccl.GroupEnd();
+                return fail(RAYZ_ERR_HIP, "ncclGather: %s", g_rccl.GetErrorString(r));
+            }
+        }
+        NCCL_TRY(g_rccl.GroupEnd());
+    } else { // peer copies, each on its source device's stream; the root's stream waits for all of them
+        for (uint32_t i = 0; i < n; ++i) {
+            DeviceScope scope(m->devices[i]);
+            HIP_TRY(hipMemcpyPeerAsync((char*)m->gathered + (size_t)i * send_bytes, m->devices[0], src(i), m->devices[i], send_bytes,
+                                       ctx[i]->stream));
+            HIP_TRY(hipEventRecord(m->done[i], ctx[i]->stream));
+        }
+        DeviceScope scope(m->devices[0]);
+        for (uint32_t i = 1; i < n; ++i) HIP_TRY(hipStreamWaitEvent(ctx[0]->stream, m->done[i], 0));
+    }
+    // 3. un-interleave on the root, copy out
+    {
+        DeviceScope scope(m->devices[0]);
+        const size_t ne = (size_t)p->height * row_elems;
+        hipLaunchKernelGGL(unshard_kernel<T>, dim3((uint32_t)((ne + 255) / 256)), dim3(256), 0, ctx[0]->stream,
+                           (const T*)m->gathered, (T*)m->frame, p->height, (uint32_t)row_elems, q.tile_rows, n, max_rows);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(out, m->frame, frame_bytes, hipMemcpyDeviceToHost, ctx[0]->stream));
+        HIP_TRY(hipStreamSynchronize(ctx[0]->stream));
+    }
+    // 4. counters: sums over the devices; kernel_ms is the slowest device's trace kernel
+    RayzRenderStats tot{};
+    for (uint32_t i = 0; i < n; ++i) {
+        RayzRenderStats st{};
+        rc = scene_sync(m->scenes[i], &st);
+        if (rc != RAYZ_OK) return rc;
+        tot.primary_rays += st.primary_rays;
+        tot.segments += st.segments;
+        tot.sphere_tests += st.sphere_tests;
+        tot.node_tests += st.node_tests;
+        tot.kernel_ms = st.kernel_ms > tot.kernel_ms ? st.kernel_ms : tot.kernel_ms;
+    }
+    if (stats) *stats = tot;
+    return RAYZ_OK;
+}
+
+template <class T>
+int render_multi_oneshot(const int* devices, int n, const RayzSceneDesc* scene, const RayzCameraDesc* cam, const RayzRenderParams* p,
+                         T* out, RayzRenderStats* stats) {
+    RayzMulti* m = nullptr;
+    int rc = rayz_hip_multi_create(devices, n, scene, RAYZ_GATHER_RCCL, &m);
+    if (rc != RAYZ_OK) return rc;
+    rc = multi_render<T>(m, cam, p, out, stats);
+    multi_free(m);
+    return rc;
+}
+
+} // namespace
+
+extern "C" {
+
+uint32_t rayz_hip_abi_version(void) { return RAYZ_HIP_ABI_VERSION; }
+const char* rayz_hip_last_error(void) { return g_err; }
+
+int rayz_hip_init(int device) {
+    return guarded([&] {
+        std::lock_guard<std::mutex> lock(g_mu);
+        const int rc = ensure_ctx(device);
+        if (rc == RAYZ_OK) g_default = device;
+        return rc;
+    });
+}
+
+void rayz_hip_shutdown(void) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    for (int d = 0; d < RAYZ_MAX_DEVICES; ++d) {
+        DeviceCtx& c = g_ctx[d];
+        if (!c.ok) continue;
+        DeviceScope scope(d);
+        (void)hipStreamSynchronize(c.stream);
+        (void)hipStreamDestroy(c.stream);
+        c = DeviceCtx{};
+    }
+    g_default = -1;
+}
+
+uint32_t rayz_hip_shard_rows(const RayzRenderParams* p) {
+    if (!p) return 0;
+    const uint32_t tr = p->tile_rows ? p->tile_rows : 8u, sc = p->shard_count ? p->shard_count : 1u;
+    if (p->shard_index >= sc) return 0;
+    uint32_t n = 0;
+    for (uint32_t t = p->shard_index; (uint64_t)t * tr < p->height; t += sc) {
+        const uint32_t r0 = t * tr;
+        n += (p->height - r0 < tr) ? p->height - r0 : tr;
+    }
+    return n;
+}
+
+uint32_t rayz_hip_chunk_spp(const RayzRenderParams* p) {
+    if (!p) return 0;
+    return p->chunk_spp ? p->chunk_spp : 16u;
+}
+
+int rayz_hip_scene_create(const RayzSceneDesc* scene, RayzScene** out) {
+    return guarded([&] { return scene_new(scene, -1, out); });
+}
+
+int rayz_hip_scene_create_on(int device, const RayzSceneDesc* scene, RayzScene** out) {
+    return guarded([&] {
+        if (out) *out = nullptr;
+        {
+            std::lock_guard<std::mutex> lock(g_mu);
+            const int rc = ensure_ctx(device);
+            if (rc != RAYZ_OK) return rc;
+        }
+        return scene_new(scene, device, out);
+    });
+}
+
+int rayz_hip_scene_destroy(RayzScene* s) {
+    return guarded([&] { return scene_free(s); });
+}
+
+int rayz_hip_render_device(RayzScene* s, const RayzCameraDesc* cam, const RayzRenderParams* p, float* d_out,
+                           void* stream) {
+    return guarded([&] { return render_device<float>(s, cam, p, d_out, stream, RAYZ_PRECISION_F32); });
+}
+
+int rayz_hip_render_device_f64(RayzScene* s, const RayzCameraDesc* cam, const RayzRenderParams* p, double* d_out,
+                               void* stream) {
+    return guarded([&] { return render_device<double>(s, cam, p, d_out, stream, RAYZ_PRECISION_F64); });
+}
+
+int rayz_hip_scene_sync(RayzScene* s, RayzRenderStats* stats) {
+    return guarded([&] { return scene_sync(s, stats); });
+}
+
 int rayz_hip_scene_bvh(RayzScene* s, uint32_t* n_nodes, uint32_t* depth, double* boxes, uint32_t* skip, uint32_t* first,
                        uint32_t* count, uint32_t* order) {
-    if (!s || !n_nodes) return fail(RAYZ_ERR_BAD_ARG, "null argument");
-    try {
+    return guarded([&] {
+        if (!s || !n_nodes) return fail(RAYZ_ERR_BAD_ARG, "null argument");
         ensure_bvh(s);
-    } catch (...) {
-        return fail(RAYZ_ERR_OOM, "host allocation failed");
-    }
-    const rayz_bvh::FlatBvh& t = s->bvh;
-    *n_nodes = (uint32_t)t.nodes.size();
-    if (depth) *depth = t.depth;
-    for (size_t i = 0; i < t.nodes.size(); ++i) {
-        if (boxes)
-            for (int k = 0; k < 3; ++k) boxes[6 * i + k] = t.nodes[i].box.lo[k], boxes[6 * i + 3 + k] = t.nodes[i].box.hi[k];
-        if (skip) skip[i] = t.nodes[i].skip;
-        if (first) first[i] = t.nodes[i].first;
-        if (count) count[i] = t.nodes[i].count;
-    }
-    if (order) std::copy(t.order.begin(), t.order.end(), order);
-    return RAYZ_OK;
+        const rayz_bvh::FlatBvh& t = s->bvh;
+        *n_nodes = (uint32_t)t.nodes.size();
+        if (depth) *depth = t.depth;
+        for (size_t i = 0; i < t.nodes.size(); ++i) {
+            if (boxes)
+                for (int k = 0; k < 3; ++k) boxes[6 * i + k] = t.nodes[i].box.lo[k], boxes[6 * i + 3 + k] = t.nodes[i].box.hi[k];
+            if (skip) skip[i] = t.nodes[i].skip;
+            if (first) first[i] = t.nodes[i].first;
+            if (count) count[i] = t.nodes[i].count;
+        }
+        if (order) std::copy(t.order.begin(), t.order.end(), order);
+        return (int)RAYZ_OK;
+    });
 }
 
 int rayz_hip_render(const RayzSceneDesc* scene, const RayzCameraDesc* cam, const RayzRenderParams* p, float* out,
                     RayzRenderStats* stats) {
-    return render_oneshot<float>(scene, cam, p, out, stats, RAYZ_PRECISION_F32);
+    return guarded([&] { return render_oneshot<float>(scene, cam, p, out, stats, RAYZ_PRECISION_F32); });
 }
 
 int rayz_hip_render_f64(const RayzSceneDesc* scene, const RayzCameraDesc* cam, const RayzRenderParams* p, double* out,
                         RayzRenderStats* stats) {
-    return render_oneshot<double>(scene, cam, p, out, stats, RAYZ_PRECISION_F64);
+    return guarded([&] { return render_oneshot<double>(scene, cam, p, out, stats, RAYZ_PRECISION_F64); });
 }
 
 int rayz_hip_tonemap_u8(const float* d_rgb, uint8_t* d_rgb8, size_t n_pixels, void* stream) {
-    if (g_device < 0) return fail(RAYZ_ERR_NO_DEVICE, "rayz_hip_init has not succeeded");
-    if (!n_pixels) return RAYZ_OK;
-    if (!d_rgb || !d_rgb8) return fail(RAYZ_ERR_BAD_ARG, "null buffer");
-    const size_t n = n_pixels * 3;
-    hipLaunchKernelGGL(tonemap_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0,
-                       stream ? (hipStream_t)stream : g_stream, d_rgb, d_rgb8, n);
-    HIP_TRY(hipGetLastError());
+    return guarded([&] {
+        int device;
+        hipStream_t own;
+        {
+            std::lock_guard<std::mutex> lock(g_mu);
+            device = g_default;
+            if (device < 0) return fail(RAYZ_ERR_NO_DEVICE, "rayz_hip_init has not succeeded");
+            own = g_ctx[device].stream;
+        }
+        if (!n_pixels) return (int)RAYZ_OK;
+        if (!d_rgb || !d_rgb8) return fail(RAYZ_ERR_BAD_ARG, "null buffer");
+        DeviceScope scope(device);
+        const size_t n = n_pixels * 3;
+        hipLaunchKernelGGL(tonemap_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream ? (hipStream_t)stream : own,
+                           d_rgb, d_rgb8, n);
+        HIP_TRY(hipGetLastError());
+        return (int)RAYZ_OK;
+    });
+}
+
+// ---- several devices behind one call ----------------------------------------------------------------------
+int rayz_hip_multi_create(const int* devices, int n_devices, const RayzSceneDesc* scene, uint32_t transport, RayzMulti** out) {
+    return guarded([&] {
+        if (!out) return fail(RAYZ_ERR_BAD_ARG, "out handle pointer is null");
+        *out = nullptr;
+        int rc = check_device_list(devices, n_devices);
+        if (rc != RAYZ_OK) return rc;
+        if (transport > RAYZ_GATHER_PEER_COPY) return fail(RAYZ_ERR_BAD_ARG, "bad gather transport %u", transport);
+        rc = validate_scene(scene);
+        if (rc != RAYZ_OK) return rc;
+        {
+            std::lock_guard<std::mutex> lock(g_mu);
+            for (int i = 0; i < n_devices; ++i) {
+                rc = ensure_ctx(devices[i]);
+                if (rc != RAYZ_OK) return rc;
+            }
+            if (transport == RAYZ_GATHER_RCCL) {
+                rc = rccl_load();
+                if (rc != RAYZ_OK) return rc;
+            }
+        }
+        RayzMulti* m = new RayzMulti();
+        m->transport = transport;
+        m->devices.assign(devices, devices + n_devices);
+        m->tile.assign(n_devices, nullptr);
+        m->tile8.assign(n_devices, nullptr);
+        m->tile_have.assign(n_devices, 0);
+        m->tile8_have.assign(n_devices, 0);
+        m->done.assign(n_devices, nullptr);
+        for (int i = 0; i < n_devices; ++i) {
+            RayzScene* s = nullptr;
+            rc = scene_new(scene, devices[i], &s);
+            if (rc != RAYZ_OK) {
+                multi_free(m);
+                return rc;
+            }
+            m->scenes.push_back(s);
+        }
+        auto bail = [&](int code) {
+            multi_free(m);
+            return code;
+        };
+        if (transport == RAYZ_GATHER_RCCL) {
+            m->comms.assign(n_devices, nullptr);
+            ncclResult_t r = g_rccl.CommInitAll(m->comms.data(), n_devices, m->devices.data());
+            if (r != ncclSuccess) {
+                m->comms.clear();
+                return bail(fail(RAYZ_ERR_HIP, "ncclCommInitAll(%d devices): %s", n_devices, g_rccl.GetErrorString(r)));
+            }
+            (void)g_rccl.GetVersion(&m->rccl_version);
+        } else {
+            for (int i = 0; i < n_devices; ++i) {
+                DeviceScope scope(devices[i]);
+                hipError_t e = hipEventCreateWithFlags(&m->done[i], hipEventDisableTiming);
+                if (e != hipSuccess) return bail(fail(RAYZ_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(e)));
+                if (i > 0) { // the root pulls nothing; sources push into the root's buffer
+                    int can = 0;
+                    (void)hipDeviceCanAccessPeer(&can, devices[i], devices[0]);
+                    if (can) {
+                        e = hipDeviceEnablePeerAccess(devices[0], 0);
+                        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+                            return bail(fail(RAYZ_ERR_HIP, "hipDeviceEnablePeerAccess(%d -> %d): %s", devices[i], devices[0],
+                                             hipGetErrorString(e)));
+                        (void)hipGetLastError();
+                    }
+                }
+            }
+        }
+        *out = m;
+        return (int)RAYZ_OK;
+    });
+}
+
+int rayz_hip_multi_destroy(RayzMulti* m) {
+    return guarded([&] { return multi_free(m); });
+}
+
+int rayz_hip_multi_info(const RayzMulti* m, int* n_devices, uint32_t* transport, int* rccl_version) {
+    if (!m) return fail(RAYZ_ERR_STATE, "multi handle is null");
+    if (n_devices) *n_devices = (int)m->devices.size();
+    if (transport) *transport = m->transport;
+    if (rccl_version) *rccl_version = m->rccl_version;
     return RAYZ_OK;
+}
+
+int rayz_hip_multi_render(RayzMulti* m, const RayzCameraDesc* cam, const RayzRenderParams* p, float* rgb_out, RayzRenderStats* stats) {
+    return guarded([&] { return multi_render<float>(m, cam, p, rgb_out, stats); });
+}
+int rayz_hip_multi_render_f64(RayzMulti* m, const RayzCameraDesc* cam, const RayzRenderParams* p, double* rgb_out,
+                              RayzRenderStats* stats) {
+    return guarded([&] { return multi_render<double>(m, cam, p, rgb_out, stats); });
+}
+int rayz_hip_multi_render_u8(RayzMulti* m, const RayzCameraDesc* cam, const RayzRenderParams* p, uint8_t* rgb8_out,
+                             RayzRenderStats* stats) {
+    return guarded([&] { return multi_render<uint8_t>(m, cam, p, rgb8_out, stats); });
+}
+
+int rayz_hip_render_multi(const int* devices, int n_devices, const RayzSceneDesc* scene, const RayzCameraDesc* cam,
+                          const RayzRenderParams* p, float* rgb_out, RayzRenderStats* stats) {
+    return guarded([&] { return render_multi_oneshot<float>(devices, n_devices, scene, cam, p, rgb_out, stats); });
+}
+int rayz_hip_render_multi_f64(const int* devices, int n_devices, const RayzSceneDesc* scene, const RayzCameraDesc* cam,
+                              const RayzRenderParams* p, double* rgb_out, RayzRenderStats* stats) {
+    return guarded([&] { return render_multi_oneshot<double>(devices, n_devices, scene, cam, p, rgb_out, stats); });
 }
 
 } // extern "C"

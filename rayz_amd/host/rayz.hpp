@@ -321,6 +321,7 @@ struct GpuOptions {
     uint64_t render_seed = 0; // else drawn from `rng` when render() starts
     uint32_t chunk_spp = 0;
     uint32_t tile_rows = 0, shard_index = 0, shard_count = 0;
+    std::vector<int> devices; // empty: the default device; else render() drives all of these (rayz_hip_render_multi)
 };
 
 static const double ASPECT_RATIO = 16.0 / 9.0; // src/renderer.zig:16
@@ -433,14 +434,18 @@ struct Tracer {
         p.shard_index = 0, p.shard_count = 1; // a Tracer owns a whole image
         const size_t n = img.h * img.w;
         int rc;
+        const bool multi = !gpu.devices.empty();
+        if (multi) p.shard_count = 0; // the library deals the rows to gpu.devices itself
         if (gpu.precision == RAYZ_PRECISION_F32) {
             std::vector<float> rgb(n * 3);
-            rc = rayz_hip_render(&sd, &cd, &p, rgb.data(), &stats);
+            rc = multi ? rayz_hip_render_multi(gpu.devices.data(), (int)gpu.devices.size(), &sd, &cd, &p, rgb.data(), &stats)
+                       : rayz_hip_render(&sd, &cd, &p, rgb.data(), &stats);
             if (rc == RAYZ_OK)
                 for (size_t i = 0; i < n; ++i) img.pixels[i] = V3{rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]};
         } else {
             std::vector<double> rgb(n * 3);
-            rc = rayz_hip_render_f64(&sd, &cd, &p, rgb.data(), &stats);
+            rc = multi ? rayz_hip_render_multi_f64(gpu.devices.data(), (int)gpu.devices.size(), &sd, &cd, &p, rgb.data(), &stats)
+                       : rayz_hip_render_f64(&sd, &cd, &p, rgb.data(), &stats);
             if (rc == RAYZ_OK)
                 for (size_t i = 0; i < n; ++i) img.pixels[i] = V3{rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]};
         }

@@ -108,6 +108,15 @@ int rayz_tracer_set_f64(RayzTracer* t, int field, double v) {
     t->t.gpu.tmin = v;
     return RAYZ_OK;
 }
+int rayz_tracer_set_devices(RayzTracer* t, const int* devices, int n) {
+    if (!t || n < 0 || (n && !devices)) return RAYZ_ERR_BAD_ARG;
+    try {
+        t->t.gpu.devices.assign(devices, devices + n);
+    } catch (...) {
+        return RAYZ_ERR_OOM;
+    }
+    return RAYZ_OK;
+}
 int rayz_tracer_info(const RayzTracer* t, RayzTracerInfo* o) {
     if (!t || !o) return RAYZ_ERR_BAD_ARG;
     o->width = (uint32_t)t->t.img.w, o->height = (uint32_t)t->t.img.h;

@@ -4,7 +4,8 @@
 //
 // Extras the reference does not have (environment variables, so the positional interface stays the
 // reference's): RAYZ_SPP, RAYZ_BOUNCES, RAYZ_SEED, RAYZ_GRID (half-width of the sphere grid, 11 in the
-// reference), RAYZ_PRECISION=f32|f64, RAYZ_TRAVERSAL=linear|bvh|auto (default auto).
+// reference), RAYZ_PRECISION=f32|f64, RAYZ_TRAVERSAL=linear|bvh|auto (default auto), RAYZ_DEVICES=0,1,...
+// (render on several GPUs of the node through rayz_hip_render_multi; default: device 0).
 #include "rayz.hpp"
 
 #include <chrono>
@@ -35,7 +36,17 @@ int main(int argc, char** argv) {
     if ((e = std::getenv("RAYZ_TRAVERSAL")))
         tracer.gpu.traversal = std::string(e) == "bvh" ? RAYZ_TRAVERSAL_BVH : std::string(e) == "linear" ? RAYZ_TRAVERSAL_LINEAR : RAYZ_TRAVERSAL_AUTO;
 
-    if (rayz_hip_init(0) != RAYZ_OK) {
+    if ((e = std::getenv("RAYZ_DEVICES"))) {
+        for (const char* q = e; *q;) {
+            char* next = nullptr;
+            const long d = std::strtol(q, &next, 10);
+            if (next == q) break;
+            tracer.gpu.devices.push_back((int)d);
+            q = *next == ',' ? next + 1 : next;
+        }
+    }
+
+    if (rayz_hip_init(tracer.gpu.devices.empty() ? 0 : tracer.gpu.devices[0]) != RAYZ_OK) {
         std::fprintf(stderr, "error: GpuRenderFailed: %s\n", rayz_hip_last_error());
         return 1;
     }

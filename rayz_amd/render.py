@@ -44,13 +44,16 @@ def render_host(scene: capi.SceneDesc, camera: capi.CameraDesc, params: capi.Ren
 
 
 class DeviceScene:
-    """A pool resident in HBM (`rayz_hip_scene_create`)."""
+    """A pool resident in HBM (`rayz_hip_scene_create`; `device` binds it to that HIP ordinal now)."""
 
-    def __init__(self, scene: capi.SceneDesc):
+    def __init__(self, scene: capi.SceneDesc, device: int | None = None):
         self._lib = capi.load()
         self._h = C.c_void_p()
-        capi.check(self._lib, self._lib.rayz_hip_scene_create(C.byref(scene), C.byref(self._h)),
-                   "rayz_hip_scene_create")
+        if device is None:
+            rc = self._lib.rayz_hip_scene_create(C.byref(scene), C.byref(self._h))
+        else:
+            rc = self._lib.rayz_hip_scene_create_on(device, C.byref(scene), C.byref(self._h))
+        capi.check(self._lib, rc, "rayz_hip_scene_create")
 
     def render_into(self, camera: capi.CameraDesc, params: capi.RenderParams, out_ptr: int, stream: int = 0) -> None:
         """Asynchronous on `stream` (a hipStream_t as int, 0 = the library's stream); `out_ptr` is device memory."""
@@ -67,6 +70,47 @@ class DeviceScene:
     def close(self) -> None:
         if self._h:
             self._lib.rayz_hip_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MultiScene:
+    """The pool replicated on several GPUs of the node (`rayz_hip_multi_create`): one call renders the whole frame —
+    rows dealt to the devices in interleaved tiles, one RCCL gather (or peer copies) to devices[0], host output."""
+
+    def __init__(self, scene: capi.SceneDesc, devices, transport: int = capi.GATHER_RCCL):
+        self._lib = capi.load()
+        self._h = C.c_void_p()
+        self.devices = list(devices)
+        arr = (C.c_int * len(self.devices))(*self.devices)
+        capi.check(self._lib, self._lib.rayz_hip_multi_create(arr, len(self.devices), C.byref(scene), transport,
+                                                              C.byref(self._h)), "rayz_hip_multi_create")
+
+    def info(self):
+        n, tr, ver = C.c_int(), C.c_uint32(), C.c_int()
+        capi.check(self._lib, self._lib.rayz_hip_multi_info(self._h, C.byref(n), C.byref(tr), C.byref(ver)),
+                   "rayz_hip_multi_info")
+        return {"n_devices": n.value, "transport": tr.value, "rccl_version": ver.value}
+
+    def render(self, camera: capi.CameraDesc, params: capi.RenderParams, u8: bool = False):
+        """Returns (frame (h, w, 3), stats); `u8` gives writePPM's bytes (tone-mapped on each device before the gather)."""
+        f64 = params.precision == capi.PRECISION_F64
+        out = np.empty((params.height, params.width, 3), dtype=np.uint8 if u8 else (np.float64 if f64 else np.float32))
+        st = capi.RenderStats()
+        fn = (self._lib.rayz_hip_multi_render_u8 if u8 else
+              self._lib.rayz_hip_multi_render_f64 if f64 else self._lib.rayz_hip_multi_render)
+        rc = fn(self._h, C.byref(camera), C.byref(params), out.ctypes.data_as(C.c_void_p), C.byref(st))
+        capi.check(self._lib, rc, "rayz_hip_multi_render")
+        return out, st
+
+    def close(self) -> None:
+        if self._h:
+            self._lib.rayz_hip_multi_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

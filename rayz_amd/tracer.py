@@ -38,6 +38,7 @@ HOST_PROTOTYPES = [
     ("rayz_tracer_add_triangle", C.c_int64, [C.c_void_p, _D, _D, _D, C.c_uint32]),
     ("rayz_tracer_set_u64", C.c_int, [C.c_void_p, C.c_int, C.c_uint64]),
     ("rayz_tracer_set_f64", C.c_int, [C.c_void_p, C.c_int, C.c_double]),
+    ("rayz_tracer_set_devices", C.c_int, [C.c_void_p, _P(C.c_int), C.c_int]),
     ("rayz_tracer_info", C.c_int, [C.c_void_p, _P(TracerInfo)]),
     ("rayz_tracer_camera", C.c_int, [C.c_void_p, _P(capi.CameraDesc)]),
     ("rayz_tracer_get_ray", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, _D, _D]),
@@ -175,7 +176,7 @@ class Tracer:
     max_bounces = property(lambda s: s.info().max_bounces, lambda s, v: s._set(FIELD_MAX_BOUNCES, v))
 
     def set_gpu(self, precision: int | None = None, traversal: int | None = None, chunk_spp: int | None = None,
-                render_seed: int | None = None, tmin: float | None = None) -> "Tracer":
+                render_seed: int | None = None, tmin: float | None = None, devices=None) -> "Tracer":
         if precision is not None:
             self._set(FIELD_PRECISION, precision)
         if traversal is not None:
@@ -186,6 +187,10 @@ class Tracer:
             self._set(FIELD_RENDER_SEED, render_seed)
         if tmin is not None:
             _lib().rayz_tracer_set_f64(self._h, FIELD_TMIN, tmin)
+        if devices is not None:  # render() then drives all of them through rayz_hip_render_multi
+            arr = (C.c_int * len(devices))(*devices)
+            if _lib().rayz_tracer_set_devices(self._h, arr, len(devices)) != capi.OK:
+                raise capi.RayzHipError(f"bad device list {devices}")
         return self
 
     # -- what render() hands to the C ABI --

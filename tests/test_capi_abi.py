@@ -34,7 +34,7 @@ def test_binding_covers_every_declared_symbol(built):
 
 def test_abi_version_and_struct_sizes(built):
     lib = capi.load()
-    assert lib.rayz_hip_abi_version() == capi.ABI_VERSION == 3
+    assert lib.rayz_hip_abi_version() == capi.ABI_VERSION == 4
     # sizes the Zig extern structs must reproduce
     assert (C.sizeof(capi.Texture), C.sizeof(capi.Material), C.sizeof(capi.Sphere)) == (48, 24, 64)
     assert (C.sizeof(capi.SceneDesc), C.sizeof(capi.CameraDesc), C.sizeof(capi.Triangle)) == (48, 152, 80)
@@ -119,3 +119,111 @@ def test_param_validation(built):
     rc = lib.rayz_hip_render(C.byref(t.scene_desc()), C.byref(t.camera_desc()), C.byref(p),
                              out.ctypes.data_as(C.c_void_p), None)
     assert rc == capi.ERR_BAD_ARG and b"precision" in lib.rayz_hip_last_error()
+
+
+def _tex_scene(textures):
+    arr = (capi.Texture * len(textures))(*textures)
+    sd = capi.SceneDesc(spheres=None, materials=None, textures=arr, n_textures=len(textures))
+    sd._keep = arr
+    return sd
+
+
+def test_checker_chains_the_device_loop_cannot_resolve_are_refused(built):
+    """The reference recurses through nested checkers without a limit (src/material.zig:36-37); the device walks a
+    bounded loop of 8 lookups.  A deeper chain or a cycle is RAYZ_ERR_BAD_ARG at scene creation, never a black pixel."""
+    lib = capi.load()
+    h = C.c_void_p()
+    solid = capi.Texture(kind=capi.TEX_SOLID, color=capi.D3(1, 1, 1))
+
+    def chain(n_checkers):  # texture 0 solid, texture k = checker(k-1, 0)
+        return [solid] + [capi.Texture(kind=capi.TEX_CHECKER, even=k - 1, odd=0, scale=1.0) for k in range(1, n_checkers + 1)]
+
+    sd = _tex_scene(chain(7))  # 7 checkers + the solid = 8 lookups: the limit
+    assert lib.rayz_hip_scene_create(C.byref(sd), C.byref(h)) == capi.OK
+    lib.rayz_hip_scene_destroy(h)
+    sd = _tex_scene(chain(8))
+    assert lib.rayz_hip_scene_create(C.byref(sd), C.byref(h)) == capi.ERR_BAD_ARG
+    assert b"nesting depth 9" in lib.rayz_hip_last_error()
+    # cycles: a checker naming itself, and a two-cycle
+    sd = _tex_scene([solid, capi.Texture(kind=capi.TEX_CHECKER, even=1, odd=0, scale=1.0)])
+    assert lib.rayz_hip_scene_create(C.byref(sd), C.byref(h)) == capi.ERR_BAD_ARG and b"cycle" in lib.rayz_hip_last_error()
+    sd = _tex_scene([solid, capi.Texture(kind=capi.TEX_CHECKER, even=0, odd=2, scale=1.0),
+                     capi.Texture(kind=capi.TEX_CHECKER, even=1, odd=0, scale=1.0)])
+    assert lib.rayz_hip_scene_create(C.byref(sd), C.byref(h)) == capi.ERR_BAD_ARG and b"cycle" in lib.rayz_hip_last_error()
+    # a diamond (two checkers sharing children) is fine
+    sd = _tex_scene([solid, solid, capi.Texture(kind=capi.TEX_CHECKER, even=0, odd=1, scale=1.0),
+                     capi.Texture(kind=capi.TEX_CHECKER, even=2, odd=2, scale=2.0),
+                     capi.Texture(kind=capi.TEX_CHECKER, even=3, odd=2, scale=3.0)])
+    assert lib.rayz_hip_scene_create(C.byref(sd), C.byref(h)) == capi.OK
+    lib.rayz_hip_scene_destroy(h)
+
+
+def test_multi_device_argument_validation(built):
+    """rayz_hip_multi_create / rayz_hip_render_multi check their arguments before touching any device."""
+    lib = capi.load()
+    t = tracer.threeSpheres(32, seed=1)
+    sd = t.scene_desc()
+    h = C.c_void_p()
+
+    def create(devs, transport=capi.GATHER_RCCL, scene=sd):
+        arr = (C.c_int * max(len(devs), 1))(*devs)
+        return lib.rayz_hip_multi_create(arr if devs is not None else None, len(devs), C.byref(scene) if scene else None,
+                                         transport, C.byref(h))
+
+    assert lib.rayz_hip_multi_create(None, 1, C.byref(sd), 0, C.byref(h)) == capi.ERR_BAD_ARG
+    assert create([]) == capi.ERR_BAD_ARG and b"n_devices" in lib.rayz_hip_last_error()
+    assert create(list(range(capi.MAX_DEVICES + 1))) == capi.ERR_BAD_ARG
+    assert create([0, 1, 0]) == capi.ERR_BAD_ARG and b"twice" in lib.rayz_hip_last_error()
+    assert create([-1]) == capi.ERR_BAD_ARG
+    assert create([0], transport=7) == capi.ERR_BAD_ARG and b"transport" in lib.rayz_hip_last_error()
+    assert create([0], scene=None) == capi.ERR_BAD_ARG
+    arr = (C.c_int * 1)(0)
+    assert lib.rayz_hip_multi_create(arr, 1, C.byref(sd), 0, None) == capi.ERR_BAD_ARG
+    assert lib.rayz_hip_multi_render(None, C.byref(t.camera_desc()), C.byref(t.params()), None, None) == capi.ERR_STATE
+    assert lib.rayz_hip_multi_destroy(None) == capi.OK
+    import torch
+
+    if not torch.cuda.is_available():  # no device here: a valid request must fail with NO_DEVICE, not compute
+        assert create([0]) == capi.ERR_NO_DEVICE
+        out = np.full((18, 32, 3), -1.0, dtype=np.float32)
+        rc = lib.rayz_hip_render_multi(arr, 1, C.byref(sd), C.byref(t.camera_desc()), C.byref(t.params()),
+                                       out.ctypes.data_as(C.c_void_p), None)
+        assert rc == capi.ERR_NO_DEVICE and (out == -1.0).all()
+        assert lib.rayz_hip_scene_create_on(0, C.byref(sd), C.byref(h)) == capi.ERR_NO_DEVICE
+        t.set_gpu(devices=[0])
+        with pytest.raises(capi.RayzHipError):
+            t.render()
+
+
+def test_errors_are_reported_per_thread(built):
+    """rayz_hip_last_error() is thread-local: two threads working on two scenes see their own messages."""
+    import threading
+
+    lib = capi.load()
+    t = tracer.threeSpheres(32, seed=1)
+    sd = t.scene_desc()
+    seen, barrier = {}, threading.Barrier(2)
+
+    def work(name, bad_material):
+        bad = (capi.Sphere * 1)(capi.Sphere(center=capi.D3(0, 0, 0), velocity=capi.D3(0, 0, 0), radius=1, material=bad_material))
+        sd2 = capi.SceneDesc(spheres=bad, materials=sd.materials, textures=sd.textures, n_spheres=1,
+                             n_materials=sd.n_materials, n_textures=sd.n_textures)
+        h = C.c_void_p()
+        for _ in range(200):
+            rc = lib.rayz_hip_scene_create(C.byref(sd2), C.byref(h))
+            barrier.wait()  # both threads have failed before either reads its message
+            msg = lib.rayz_hip_last_error()
+            if rc != capi.ERR_BAD_ARG or f"material handle {bad_material}".encode() not in msg:
+                seen[name] = (rc, msg)
+                barrier.abort()
+                return
+            try:
+                barrier.wait()
+            except threading.BrokenBarrierError:
+                return
+        seen[name] = "ok"
+
+    ths = [threading.Thread(target=work, args=("a", 111)), threading.Thread(target=work, args=("b", 222))]
+    [x.start() for x in ths]
+    [x.join() for x in ths]
+    assert seen == {"a": "ok", "b": "ok"}, seen
