@@ -264,6 +264,37 @@ int rayz_hip_render_multi_f64(const int* devices, int n_devices, const RayzScene
  * n_pixels*3 floats in, n_pixels*3 bytes out. */
 int rayz_hip_tonemap_u8(const float* d_rgb, uint8_t* d_rgb8, size_t n_pixels, void* hip_stream); /* default device */
 
+/* ---- known answers ---------------------------------------------------------------------------------------------
+ * Evaluates the trace kernels' OWN device functions (the same inlined code the kernels run) on caller inputs, one
+ * GPU thread per record, so that the reference's test vectors and a CPU restatement can be held against the
+ * device code directly: src/material.zig:213-223 (refract), src/renderer.zig:129-149 (get ray),
+ * src/hit.zig:247-279 (bbox hit); tests/test_kat_gpu.py.  Host buffers: `in` = n records of RAYZ_KAT_IN_STRIDE
+ * doubles, `out` = n records of RAYZ_KAT_OUT_STRIDE doubles (unused slots 0).  Values are narrowed to `precision`
+ * as a scene is when it crosses the ABI.  Random draws, where an op makes any, come from the record's list u[]
+ * (0.5 beyond its end) in the order the path would make them.  Default device. */
+typedef enum RayzKatOp {
+    RAYZ_KAT_REFRACT = 0,     /* in: unit_dir[0..2] normal[3..5] eta[6]            out: dir[0..2]       src/material.zig:189-194 */
+    RAYZ_KAT_REFLECTANCE = 1, /* in: cos[0] ri[1]                                  out: r[0]            src/material.zig:179-183 */
+    RAYZ_KAT_GET_RAY = 2,     /* in: look_from px_du px_dv px_origin defocus_u defocus_v [0..17] defocus[18] px[19] py[20]
+                                     n_u[21] u[22..]; n_u = 0 is NOT getRay(px,py,null): the kernel always draws
+                                 out: origin[0..2] dir[3..5] time[6] draws[7]                           src/camera.zig:59-90 */
+    RAYZ_KAT_BOX_HIT = 3,     /* in: low[0..2] high[3..5] origin[6..8] dir[9..11] tmin[12] tmax[13]
+                                 out: hit[0] t_entry[1]                                                 src/hit.zig:70-98 */
+    RAYZ_KAT_SPHERE_HIT = 4,  /* in: center[0..2] velocity[3..5] radius[6] origin[7..9] dir[10..12] time[13] tmin[14] tmax[15]
+                                 out: hit[0] t[1] point[2..4] normal[5..7] front_face[8] passed_filter[9]
+                                                                                        src/geom.zig:38-66, src/hit.zig:25-41 */
+    RAYZ_KAT_SCATTER = 5,     /* in: kind[0] method[1] param[2] ray origin[3..5] dir[6..8] hit point[9..11] normal[12..14]
+                                     front_face[15] n_u[16] u[17..]
+                                 out: scattered[0] dir[1..3] draws[4]                                   src/material.zig:73-160 */
+    RAYZ_KAT_CHECKER = 6,     /* in: point[0..2] scale[3]                          out: parity[0]       src/material.zig:32-36 */
+    RAYZ_KAT_BACKGROUND = 7,  /* in: dir[0..2]                                     out: colour[0..2]    src/renderer.zig:124-125 */
+    RAYZ_KAT_TRIANGLE_HIT = 8 /* in: v0[0..2] v1[3..5] v2[6..8] origin[9..11] dir[12..14] tmin[15] tmax[16]
+                                 out: hit[0] t[1] passed_filter[2]                 build-defined */
+} RayzKatOp;
+#define RAYZ_KAT_IN_STRIDE 48
+#define RAYZ_KAT_OUT_STRIDE 12
+int rayz_hip_kat(uint32_t op, uint32_t precision, const double* in, uint32_t n_records, double* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -41,6 +41,9 @@ def load() -> C.CDLL:
         "rayz_oracle_render_b_f32": (C.c_int, [S, Cm, Pm, _P(C.c_uint32), C.c_uint32, C.c_void_p, St, C.c_int]),
         "rayz_oracle_render_b_f64": (C.c_int, [S, Cm, Pm, _P(C.c_uint32), C.c_uint32, C.c_void_p, St, C.c_int]),
         "rayz_oracle_shard_rows": (C.c_uint32, [Pm]),
+        "rayz_oracle_kat_b": (C.c_int, [C.c_uint32, C.c_uint32, _D, C.c_uint32, _D]),
+        "rayz_oracle_kat_a": (C.c_int, [C.c_uint32, _D, C.c_uint32, _D]),
+        "rayz_oracle_filter_audit": (C.c_int, [S, Cm, Pm, C.c_uint32, _P(C.c_uint32), C.c_uint32, _U64]),
         "rayz_oracle_render_a": (C.c_int, [S, Cm, Pm, C.c_uint32, C.c_uint32, _U64, C.c_int, _D, _D, St]),
         "rayz_oracle_bvh_flat": (C.c_uint32, [S, _D, _P(C.c_uint32), _P(C.c_uint32), _P(C.c_uint32), _P(C.c_uint32)]),
         "rayz_oracle_camera_init": (None, [C.c_double, C.c_double, C.c_double, _D, _D, _D, C.c_uint32, C.c_uint32, Cm]),
@@ -75,6 +78,33 @@ def load() -> C.CDLL:
 
 def d3(v) -> C.Array:
     return capi.D3(*[float(x) for x in v])
+
+
+def kat_b(op: int, records: np.ndarray, precision: int = capi.PRECISION_F64) -> np.ndarray:
+    """Mode B's pieces on rayz_hip_kat records: (n, KAT_IN_STRIDE) float64 -> (n, KAT_OUT_STRIDE)."""
+    rec = np.ascontiguousarray(records, dtype=np.float64).reshape(-1, capi.KAT_IN_STRIDE)
+    out = np.zeros((len(rec), capi.KAT_OUT_STRIDE))
+    rc = load().rayz_oracle_kat_b(op, precision, rec.ctypes.data_as(_D), len(rec), out.ctypes.data_as(_D))
+    assert rc == 0, rc
+    return out
+
+
+def kat_a(op: int, records: np.ndarray) -> np.ndarray:
+    """The same records through mode A (the reference's own functions, f64)."""
+    rec = np.ascontiguousarray(records, dtype=np.float64).reshape(-1, capi.KAT_IN_STRIDE)
+    out = np.zeros((len(rec), capi.KAT_OUT_STRIDE))
+    rc = load().rayz_oracle_kat_a(op, rec.ctypes.data_as(_D), len(rec), out.ctypes.data_as(_D))
+    assert rc == 0, rc
+    return out
+
+
+def filter_audit(scene, camera, params, pixels, precision: int = capi.PRECISION_F32) -> dict:
+    pl = np.ascontiguousarray(pixels, dtype=np.uint32)
+    out = np.zeros(5, dtype=np.uint64)
+    rc = load().rayz_oracle_filter_audit(C.byref(scene), C.byref(camera), C.byref(params), precision,
+                                         pl.ctypes.data_as(_P(C.c_uint32)), len(pl), out.ctypes.data_as(_U64))
+    assert rc == 0, rc
+    return dict(zip(("pairs", "candidates", "f64_hits", "false_negatives", "unpadded_false_negatives"), map(int, out)))
 
 
 def render_b(scene, camera, params, pixels=None, threads: int = 0):

@@ -183,7 +183,18 @@ struct V3 {
     }
 };
 static V3 v3(const double* p) { return {p[0], p[1], p[2]}; }
-static V3 v3random(Xoshiro256pp& r, double lo, double hi) {                  // src/vec.zig:9-16
+// The reference's functions take a `std.Random`; here the generator type is a template parameter so that the
+// known-answer entry can hand the SAME functions a list of uniforms instead of the xoshiro stream.
+struct ListRng {
+    const double* u;
+    u32 n, i;
+    double float64() {
+        const double v = i < n ? u[i] : 0.5;
+        ++i;
+        return v;
+    }
+};
+template <class G> static V3 v3random(G& r, double lo, double hi) {          // src/vec.zig:9-16
     const double scale = hi - lo;
     V3 v;
     v.x = r.float64() * scale + lo;
@@ -369,26 +380,34 @@ struct BVH {                                                                 // 
     }
 };
 
+// src/material.zig:32-36: which of a checker's two textures covers `point`
+static int64_t checkerParity(V3 point, double scale) {
+    const int64_t x = (int64_t)std::floor(point.x / scale);
+    const int64_t y = (int64_t)std::floor(point.y / scale);
+    const int64_t z = (int64_t)std::floor(point.z / scale);
+    const int64_t s = x + y + z;
+    return ((s % 2) + 2) % 2; // @mod: floored
+}
 // src/material.zig:19-51
 static V3 textureValue(const Scene& sc, u32 idx, V3 point) {
     const RayzTexture& t = sc.textures[idx];
     if (t.kind == RAYZ_TEX_SOLID) return v3(t.color);
-    const int64_t x = (int64_t)std::floor(point.x / t.scale);
-    const int64_t y = (int64_t)std::floor(point.y / t.scale);
-    const int64_t z = (int64_t)std::floor(point.z / t.scale);
-    const int64_t s = x + y + z;
-    const int64_t m = ((s % 2) + 2) % 2; // @mod: floored
-    return textureValue(sc, m == 0 ? t.even : t.odd, point);
+    return textureValue(sc, checkerParity(point, t.scale) == 0 ? t.even : t.odd, point);
+}
+// src/renderer.zig:124-125 (not a lerp)
+static V3 background(V3 dir) {
+    const double t = 0.5 * (dir.unit().y + 1.0);
+    return V3::of(1).mul(1.0 - t).add(V3{0.5, 0.7, 1.0}).mul(t);
 }
 
-static V3 randomInUnitSphere(Xoshiro256pp& r) {                              // src/material.zig:196-202
+template <class G> static V3 randomInUnitSphere(G& r) {                      // src/material.zig:196-202
     for (;;) {
         const V3 v = v3random(r, -1, 1);
         if (v.mag() <= 1) return v;
     }
 }
-static V3 randomUnit(Xoshiro256pp& r) { return randomInUnitSphere(r).unit(); }      // :204-206
-static V3 randomInHemisphere(Xoshiro256pp& r, V3 n) {                        // :208-211
+template <class G> static V3 randomUnit(G& r) { return randomInUnitSphere(r).unit(); } // :204-206
+template <class G> static V3 randomInHemisphere(G& r, V3 n) {                // :208-211
     const V3 v = randomInUnitSphere(r);
     return v.dot(n) > 0 ? v : v.mul(-1);
 }
@@ -413,7 +432,8 @@ struct Scatter {
     V3 att;
 };
 
-static Scatter scatter(const Scene& sc, const RayzMaterial& m, Xoshiro256pp& rng, const Ray& ray, const Hit& hit) {
+template <class G>
+static Scatter scatter(const Scene& sc, const RayzMaterial& m, G& rng, const Ray& ray, const Hit& hit) {
     Scatter s;
     if (m.kind == RAYZ_MAT_DIFFUSE) {                                        // src/material.zig:77-101
         V3 target;
@@ -479,7 +499,7 @@ struct Camera {                                                              // 
         c.defocus = defocus_angle > 0;
         return c;
     }
-    V3 randomInDefocus(Xoshiro256pp& r) const {                              // :79-90
+    template <class G> V3 randomInDefocus(G& r) const {                      // :79-90
         if (!defocus) return V3{};
         for (;;) {
             V3 v;
@@ -489,7 +509,7 @@ struct Camera {                                                              // 
             if (v.dot(v) <= 1) return defocus_u.mul(v.x).add(defocus_v.mul(v.y));
         }
     }
-    Ray getRay(size_t px, size_t py, Xoshiro256pp* r) const {                // :59-77
+    template <class G> Ray getRay(size_t px, size_t py, G* r) const {        // :59-77
         double x = (double)px, y = (double)py;
         V3 origin = look_from;
         if (r) {
@@ -562,8 +582,7 @@ struct Tracer {                                                              // 
             if (s.ok) ret = bounceRay(s.ray, depth - 1).vmul(s.att);
             return ret;
         }
-        const double t = 0.5 * (ray.dir.unit().y + 1.0);
-        return V3::of(1).mul(1.0 - t).add(V3{0.5, 0.7, 1.0}).mul(t);
+        return background(ray.dir);
     }
 };
 
@@ -606,7 +625,8 @@ template <class R> struct Mat {
 };
 template <class R> struct Sph {
     V<R> c;     // broad phase, narrowed to R
-    R r2;
+    R r2;       // PADDED square of the conservative filter: (r + E)² rounded up, padRadius2()
+    double radius;
     V<R> v;
     double c64[3], v64[3], r2_64; // narrow phase: the pool's own f64 values
     u32 mat;
@@ -639,7 +659,28 @@ template <class R> struct CamB {
 
 template <class R> static V<R> narrow3(const double* p) { return {(R)p[0], (R)p[1], (R)p[2]}; }
 
-template <class R> static SceneB<R> buildScene(const RayzSceneDesc& d) {
+template <class R> static R roundUp(double v);
+static double norm3(const double* v) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
+// Conservative reject filter: r_pad = r + E, E = 32·u·(|c| + |v| + r + S); u = unit roundoff of R,
+// S = a bound on |o| of every ray.  Restated here, not shared with the product.
+template <class R> static R padRadius2(const RayzSphere& q, double S) {
+    const double u = (double)std::numeric_limits<R>::epsilon() / 2;
+    const double E = 32.0 * u * (norm3(q.center) + norm3(q.velocity) + std::fabs(q.radius) + S);
+    const double rp = std::fabs(q.radius) + E;
+    return roundUp<R>(rp * rp);
+}
+static double originBound(const RayzSceneDesc& d, const RayzCameraDesc* c) {
+    double S = 0;
+    for (u32 i = 0; i < d.n_spheres; ++i)
+        S = std::max(S, norm3(d.spheres[i].center) + norm3(d.spheres[i].velocity) + std::fabs(d.spheres[i].radius));
+    for (u32 i = 0; i < d.n_triangles; ++i)
+        S = std::max({S, norm3(d.triangles[i].v0), norm3(d.triangles[i].v1), norm3(d.triangles[i].v2)});
+    S *= 1.0 + 1e-3;
+    if (c) S = std::max(S, norm3(c->look_from) + norm3(c->defocus_u) + norm3(c->defocus_v));
+    return S;
+}
+
+template <class R> static SceneB<R> buildScene(const RayzSceneDesc& d, double S) {
     SceneB<R> s;
     for (int pass = 0; pass < 2; ++pass) {
         for (u32 i = 0; i < d.n_spheres; ++i) {
@@ -649,8 +690,8 @@ template <class R> static SceneB<R> buildScene(const RayzSceneDesc& d) {
             Sph<R> o;
             o.c = narrow3<R>(q.center);
             o.v = narrow3<R>(q.velocity);
-            const R r = (R)q.radius;
-            o.r2 = r * r;
+            o.r2 = padRadius2<R>(q, S);
+            o.radius = q.radius;
             for (int k = 0; k < 3; ++k) o.c64[k] = q.center[k], o.v64[k] = q.velocity[k];
             o.r2_64 = q.radius * q.radius;
             o.mat = q.material;
@@ -761,7 +802,20 @@ template <class R> static CamB<R> buildCamera(const RayzCameraDesc& d) {
 static const int kMaxRejectionTries = 64;
 static const int kMaxTextureDepth = 8;
 
-template <class R> static V<R> randomInUnitSphere(Rng<R>& g) {               // src/material.zig:196-202
+// ---- the pieces of the kernel arithmetic, one function each.  tracePath() below strings them together
+// exactly as the trace kernels do; the known-answer entry (rayz_oracle_kat_b) calls them one at a time, as
+// rayz_hip_kat does with their device twins. -----------------------------------------------------------------------
+template <class R> struct ListRng { // draws from a list (0.5 beyond its end): known-answer entry only
+    const double* u;
+    u32 n, i;
+    R uniform() {
+        const R v = i < n ? (R)u[i] : R(0.5);
+        ++i;
+        return v;
+    }
+};
+
+template <class R, class G> static V<R> randomInUnitSphere(G& g) {           // src/material.zig:196-202
     V<R> v{0, 0, 0};
     for (int i = 0; i < kMaxRejectionTries; ++i) {
         v.x = fm(g.uniform(), R(2), R(-1));                                  // V3.random x,y,z order, src/vec.zig:9-16
@@ -772,21 +826,211 @@ template <class R> static V<R> randomInUnitSphere(Rng<R>& g) {               // 
     return v;
 }
 
+template <class R> static u32 checkerParity(V<R> p, R scale) {               // src/material.zig:32-36
+    const R lim = R(1073741824.0);
+    auto cell = [&](R c) {
+        R f = std::floor(c / scale);
+        f = f < -lim ? -lim : f;
+        f = f > lim ? lim : f;
+        return (int32_t)f;
+    };
+    const u32 s = (u32)cell(p.x) + (u32)cell(p.y) + (u32)cell(p.z);
+    return s & 1u;
+}
 template <class R> static V<R> textureValue(const SceneB<R>& sc, u32 idx, V<R> p) { // src/material.zig:19-51
     for (int depth = 0; depth < kMaxTextureDepth; ++depth) {
         const Tex<R>& t = sc.texs[idx];
         if (t.kind == RAYZ_TEX_SOLID) return t.color;
-        const R lim = R(1073741824.0);
-        auto cell = [&](R c) {
-            R f = std::floor(c / t.scale);
-            f = f < -lim ? -lim : f;
-            f = f > lim ? lim : f;
-            return (int32_t)f;
-        };
-        const int32_t s = (int32_t)((u32)cell(p.x) + (u32)cell(p.y) + (u32)cell(p.z));
-        idx = (s & 1) == 0 ? t.even : t.odd;
+        idx = checkerParity<R>(p, t.scale) == 0 ? t.even : t.odd;
     }
     return V<R>{0, 0, 0};
+}
+
+template <class R> static V<R> background(V<R> ud) {                         // src/renderer.zig:124-125
+    const R t = R(0.5) * (ud.y + R(1));
+    const R w = R(1) - t;
+    return {(w + R(0.5)) * t, (w + R(0.7)) * t, (w + R(1.0)) * t};
+}
+
+// camera ray, src/camera.zig:59-90 (draw order: jitter x, jitter y, lens tries, time)
+template <class R, class G>
+static void cameraRay(const CamB<R>& cam, G& g, u32 px, u32 py, V<R>& o, V<R>& d, R& time) {
+    const R x = (R)px + (g.uniform() - R(0.5));
+    const R y = (R)py + (g.uniform() - R(0.5));
+    o = cam.from;
+    if (cam.defocus) {                                                       // :79-90
+        R vx = 0, vy = 0;
+        for (int i = 0; i < kMaxRejectionTries; ++i) {
+            vx = fm(g.uniform(), R(2), R(-1));
+            vy = fm(g.uniform(), R(2), R(-1));
+            if (fm(vy, vy, vx * vx) <= R(1)) break;
+        }
+        o.x = cam.from.x + fm(cam.defv.x, vy, cam.defu.x * vx);
+        o.y = cam.from.y + fm(cam.defv.y, vy, cam.defu.y * vx);
+        o.z = cam.from.z + fm(cam.defv.z, vy, cam.defu.z * vx);
+    }
+    d.x = (fm(cam.dv.x, y, cam.du.x * x) + cam.pxo.x) - o.x;
+    d.y = (fm(cam.dv.y, y, cam.du.y * x) + cam.pxo.y) - o.y;
+    d.z = (fm(cam.dv.z, y, cam.du.z * x) + cam.pxo.z) - o.z;
+    time = g.uniform();
+}
+
+// Reject-test basis: e1 ⟂ ud in the xz-plane, e2 = ud × e1.  The squared distance from the
+// line to a centre c is p1² + p2² with p1 = c·e1 + k1, p2 = c·e2 + k2; e1.y = 0, so a y-velocity never enters p1.
+template <class R> struct Basis {
+    R e1x, e1z, e2x, e2y, e2z, k1, k2;
+};
+template <class R> static Basis<R> makeBasis(V<R> ud, V<R> o) {
+    Basis<R> b;
+    const R h2 = fm(ud.z, ud.z, ud.x * ud.x);
+    b.e1x = R(1), b.e1z = R(0);
+    if (h2 > R(1e-30)) {
+        const R ih = R(1) / std::sqrt(h2);
+        b.e1x = ud.z * ih;
+        b.e1z = -(ud.x * ih);
+    }
+    b.e2x = ud.y * b.e1z, b.e2y = fm(ud.z, b.e1x, -(ud.x * b.e1z)), b.e2z = -(ud.y * b.e1x);
+    b.k1 = -fm(o.z, b.e1z, o.x * b.e1x);
+    b.k2 = -fm(o.z, b.e2z, fm(o.y, b.e2y, o.x * b.e2x));
+    return b;
+}
+// r_pad² − p1² − p2² in R: ≥ 0 makes the sphere a candidate.  `r2` is the PADDED square (padRadius2), which makes
+// the filter conservative.  A zero velocity component is skipped (fm(0, x, p) = p: same bits as the device's
+// unconditional form).
+template <class R> static R sphereFilter(const Basis<R>& b, R time, V<R> c, V<R> v, R r2) {
+    R p1 = fm(c.z, b.e1z, fm(c.x, b.e1x, b.k1));
+    if (v.x != R(0)) p1 = fm(v.x, time * b.e1x, p1);
+    if (v.z != R(0)) p1 = fm(v.z, time * b.e1z, p1);
+    R p2 = fm(c.z, b.e2z, fm(c.y, b.e2y, fm(c.x, b.e2x, b.k2)));
+    if (v.x != R(0)) p2 = fm(v.x, time * b.e2x, p2);
+    if (v.y != R(0)) p2 = fm(v.y, time * b.e2y, p2);
+    if (v.z != R(0)) p2 = fm(v.z, time * b.e2z, p2);
+    return fm(-p1, p1, fm(-p2, p2, r2));
+}
+// narrow phase: the reference's quadratic (src/geom.zig:40-58) in f64 on the f64 sphere, for the ray as the kernel
+// holds it; the chosen root is rounded to R before the comparisons.  Returns the f64 discriminant.
+template <class R>
+static double narrowRoots(const double* c64, const double* v64, double r2_64, V<R> o, V<R> d, R time, R tmin, int pool, R& tbest,
+                          int& ibest) {
+    const double dx = d.x, dy = d.y, dz = d.z, tm = time;
+    const double a2 = std::fma(dz, dz, std::fma(dy, dy, dx * dx));
+    const double inv_a2 = 1.0 / a2;
+    double qx = c64[0] - (double)o.x, qy = c64[1] - (double)o.y, qz = c64[2] - (double)o.z;
+    qx = std::fma(v64[0], tm, qx);
+    qy = std::fma(v64[1], tm, qy);
+    qz = std::fma(v64[2], tm, qz);
+    const double hb2 = std::fma(dz, qz, std::fma(dy, qy, dx * qx));
+    const double cc2 = std::fma(qz, qz, std::fma(qy, qy, std::fma(qx, qx, -r2_64)));
+    const double disc2 = std::fma(-a2, cc2, hb2 * hb2);
+    if (!(disc2 >= 0.0)) return disc2;
+    const double rt = std::sqrt(disc2);
+    const R t1 = (R)((hb2 - rt) * inv_a2), t2 = (R)((hb2 + rt) * inv_a2);
+    const R t = t1 >= tmin ? t1 : t2;
+    if (t >= tmin && (t < tbest || (t == tbest && pool > ibest))) {
+        tbest = t;
+        ibest = pool;
+    }
+    return disc2;
+}
+// hit record, src/geom.zig:63-65 + src/hit.zig:25-41
+template <class R> static void sphereHitRecord(V<R> c, V<R> v, V<R> o, V<R> d, R time, R t, V<R>& pt, V<R>& nrm) {
+    pt = {fm(d.x, t, o.x), fm(d.y, t, o.y), fm(d.z, t, o.z)};
+    const V<R> cn{fm(v.x, time, c.x), fm(v.y, time, c.y), fm(v.z, time, c.z)};
+    nrm = unit(V<R>{pt.x - cn.x, pt.y - cn.y, pt.z - cn.z});
+}
+template <class R> static bool faceForward(V<R> d, V<R>& nrm) {              // Hit.init, src/hit.zig:33-36
+    const bool front = dot3(nrm, d) < R(0);
+    if (!front) nrm = neg(nrm);
+    return front;
+}
+template <class R> static R reflectance(R cosv, R eta) {                     // src/material.zig:179-183, pow(x,5) → x²·x²·x
+    R r0 = (R(1) - eta) / (R(1) + eta);
+    r0 = r0 * r0;
+    const R xx = R(1) - cosv;
+    const R x2 = xx * xx;
+    const R x5 = (x2 * x2) * xx;
+    return fm(R(1) - r0, x5, r0);
+}
+template <class R> static V<R> reflect(V<R> d, V<R> nrm) {                   // :185-187, unnormalised d
+    const R k = R(2) * dot3(d, nrm);
+    return {fm(-k, nrm.x, d.x), fm(-k, nrm.y, d.y), fm(-k, nrm.z, d.z)};
+}
+template <class R> static V<R> refract(V<R> ud, V<R> nrm, R cosv, R eta) {   // :189-194
+    const V<R> perp{fm(nrm.x, cosv, ud.x) * eta, fm(nrm.y, cosv, ud.y) * eta, fm(nrm.z, cosv, ud.z) * eta};
+    // clamped at 0: see DESIGN.md §4.5 (f32 rounds 1 − |perp|² below 0 near the critical angle)
+    const R sp = -std::sqrt(std::fmax(R(1) - dot3(perp, perp), R(0)));
+    return {fm(nrm.x, sp, perp.x), fm(nrm.y, sp, perp.y), fm(nrm.z, sp, perp.z)};
+}
+// `Material.scatter` without the texture lookup: false = absorbed
+template <class R, class G>
+static bool scatterDir(u32 kind, u32 method, R param, R inv_param, G& g, V<R> d, V<R> ud, V<R> pt, V<R> nrm, bool front,
+                       V<R>& nd) {
+    if (kind == RAYZ_MAT_DIFFUSE) {                                          // src/material.zig:77-101
+        V<R> target;
+        V<R> r = randomInUnitSphere<R>(g);
+        if (method == RAYZ_DIFFUSE_HEMISPHERE) {
+            if (!(dot3(r, nrm) > R(0))) r = neg(r);                          // :208-211
+            target = {pt.x + r.x, pt.y + r.y, pt.z + r.z};
+        } else {
+            if (method == RAYZ_DIFFUSE_UNIT_SPHERE_SURFACE) r = unit(r);
+            target = {(pt.x + nrm.x) + r.x, (pt.y + nrm.y) + r.y, (pt.z + nrm.z) + r.z};
+        }
+        const R tol = (R)1e-8;
+        if (std::fabs(target.x) <= tol && std::fabs(target.y) <= tol && std::fabs(target.z) <= tol)
+            target = nrm;                                                    // :85-86 (tests the POINT; preserved)
+        nd = {target.x - pt.x, target.y - pt.y, target.z - pt.z};
+    } else if (kind == RAYZ_MAT_METALLIC) {                                  // :108-131
+        V<R> r = unit(reflect<R>(d, nrm));
+        if (param > R(0)) {
+            const V<R> ru = unit(randomInUnitSphere<R>(g));
+            const R f = param < R(1) ? param : R(1);
+            r = {fm(ru.x, f, r.x), fm(ru.y, f, r.y), fm(ru.z, f, r.z)};
+        }
+        if (dot3(r, nrm) <= R(0)) return false;                              // absorbed → black
+        nd = r;
+    } else {                                                                 // :137-159
+        const R eta = front ? inv_param : param;
+        const R cosv = -dot3(ud, nrm);
+        const R sinv = std::sqrt(fm(-cosv, cosv, R(1)));
+        bool refl = eta * sinv > R(1);
+        if (!refl) refl = reflectance<R>(cosv, eta) > g.uniform();           // the draw only when not TIR, :145
+        nd = refl ? reflect<R>(d, nrm) : refract<R>(ud, nrm, cosv, eta);
+    }
+    return true;
+}
+// build-defined triangle: sign-free barycentric test in R, then t = (e2·q) / det
+template <class R> static R triFilter(V<R> v0, V<R> e1, V<R> e2, V<R> o, V<R> d) {
+    const V<R> pv = cross3(d, e2);
+    const R det = dot3(e1, pv);
+    const V<R> sv{o.x - v0.x, o.y - v0.y, o.z - v0.z};
+    const R su = dot3(sv, pv) * det;
+    const V<R> qv = cross3(sv, e1);
+    const R svv = dot3(d, qv) * det;
+    const R w = fm(det, det, -(su + svv));
+    return std::fmin(std::fmin(su, svv), w);
+}
+template <class R> static void triAccept(R filt, V<R> v0, V<R> e1, V<R> e2, V<R> o, V<R> d, R tmin, int prim, R& tbest, int& ibest) {
+    if (!(filt >= R(0))) return;
+    const V<R> pv = cross3(d, e2);
+    const R det = dot3(e1, pv);
+    if (det == R(0)) return;
+    const V<R> sv{o.x - v0.x, o.y - v0.y, o.z - v0.z};
+    const V<R> qv = cross3(sv, e1);
+    const R t = dot3(e2, qv) / det;
+    if (t >= tmin && (t < tbest || (t == tbest && prim > ibest))) {
+        tbest = t;
+        ibest = prim;
+    }
+}
+// slab test, src/hit.zig:70-98, with 1/d hoisted and a 4-ulp slack (never culls a box the f64 narrow phase would hit)
+template <class R> static bool boxHit(const R* lo, const R* hi, V<R> inv, V<R> o, R tmin, R tbest, R& t0) {
+    const R slack = R(1) + R(4) * std::numeric_limits<R>::epsilon();
+    const R ax = (lo[0] - o.x) * inv.x, bx = (hi[0] - o.x) * inv.x;
+    const R ay = (lo[1] - o.y) * inv.y, by = (hi[1] - o.y) * inv.y;
+    const R az = (lo[2] - o.z) * inv.z, bz = (hi[2] - o.z) * inv.z;
+    t0 = std::fmax(std::fmax(std::fmin(ax, bx), std::fmin(ay, by)), std::fmax(std::fmin(az, bz), tmin));
+    const R t1 = std::fmin(std::fmin(std::fmax(ax, bx), std::fmax(ay, by)), std::fmin(std::fmax(az, bz), tbest));
+    return t1 * slack >= t0;
 }
 
 // RAYZ_TRAVERSAL_AUTO (include/rayz_hip.h): flat list up to RAYZ_AUTO_BVH_MIN hittables, BVH above
@@ -799,35 +1043,23 @@ template <class R> struct PathResult {
     u32 segments;
     u64 node_tests, sphere_tests;
 };
+// What the filter audit counts over a flat-list render (tests/test_filter_conservative.py): for every (segment,
+// sphere) pair the f64 discriminant the narrow phase would compute, against the R filter's verdict.
+struct FilterAudit {
+    u64 pairs = 0, candidates = 0, f64_hits = 0, false_negatives = 0, unpadded_false_negatives = 0;
+};
 
 template <class R>
 static PathResult<R> tracePath(const SceneB<R>& sc, const CamB<R>& cam, const RayzRenderParams& p, u32 px, u32 py,
-                               u32 s) {
+                               u32 s, FilterAudit* audit = nullptr) {
     const R tmin = (R)p.tmin;
     Rng<R> g;
     const u64 pixel_index = (u64)py * p.width + px;
     g.g.seed_path(p.seed, pixel_index * p.samples_per_px + s);
 
-    // --- camera ray, src/camera.zig:59-77 ---
-    const R x = (R)px + (g.uniform() - R(0.5));
-    const R y = (R)py + (g.uniform() - R(0.5));
-    V<R> o = cam.from;
-    if (cam.defocus) {                                                       // :79-90
-        R vx = 0, vy = 0;
-        for (int i = 0; i < kMaxRejectionTries; ++i) {
-            vx = fm(g.uniform(), R(2), R(-1));
-            vy = fm(g.uniform(), R(2), R(-1));
-            if (fm(vy, vy, vx * vx) <= R(1)) break;
-        }
-        o.x = cam.from.x + fm(cam.defv.x, vy, cam.defu.x * vx);
-        o.y = cam.from.y + fm(cam.defv.y, vy, cam.defu.y * vx);
-        o.z = cam.from.z + fm(cam.defv.z, vy, cam.defu.z * vx);
-    }
-    V<R> d;
-    d.x = (fm(cam.dv.x, y, cam.du.x * x) + cam.pxo.x) - o.x;
-    d.y = (fm(cam.dv.y, y, cam.du.y * x) + cam.pxo.y) - o.y;
-    d.z = (fm(cam.dv.z, y, cam.du.z * x) + cam.pxo.z) - o.z;
-    const R time = g.uniform();
+    V<R> o, d;
+    R time;
+    cameraRay<R>(cam, g, px, py, o, d, time);
 
     V<R> thr{1, 1, 1};
     PathResult<R> res{{0, 0, 0}, 0, 0, 0};
@@ -835,95 +1067,45 @@ static PathResult<R> tracePath(const SceneB<R>& sc, const CamB<R>& cam, const Ra
 
     for (u32 seg = 0; seg < p.max_bounces; ++seg) {                          // src/renderer.zig:103-126, iterative
         res.segments++;
-        // --- nearest hit over the flat list, src/geom.zig:38-66 per sphere ---
-        // Reject test in R with the UNIT direction (disc/a ≥ 0 ⟺ disc ≥ 0); candidates go to the narrow
-        // phase in f64.  Ties in t go to the larger pool index — what the reference's "t ≤ maxt, later wins"
-        // gives over its flat hittable list (src/hit.zig:208-214) — so the result does not depend on the
-        // order in which the spheres are scanned.
+        // --- nearest hit, src/geom.zig:38-66 per sphere ---
+        // Reject test in R with the UNIT direction; candidates go to the narrow phase in f64.  Ties in t go to the
+        // larger pool index — what the reference's "t ≤ maxt, later wins" gives over its flat hittable list
+        // (src/hit.zig:208-214) — so the result does not depend on the order in which the spheres are examined.
         const V<R> ud = unit(d);
-        const double dx = d.x, dy = d.y, dz = d.z, tm = time;
-        const double a2 = std::fma(dz, dz, std::fma(dy, dy, dx * dx));
-        const double inv_a2 = 1.0 / a2;
         R tbest = inf;
         int ibest = -1;
-        // Reject-test basis: e1 ⟂ ud in the xz-plane, e2 = ud × e1.  The squared
-        // distance from the line to a centre c is p1² + p2² with p1 = c·e1 + k1, p2 = c·e2 + k2; e1.y = 0, so a
-        // y-velocity never enters p1.
-        const R h2 = fm(ud.z, ud.z, ud.x * ud.x);
-        R e1x = R(1), e1z = R(0);
-        if (h2 > R(0)) {
-            const R ih = R(1) / std::sqrt(h2);
-            e1x = ud.z * ih;
-            e1z = -(ud.x * ih);
-        }
-        const R e2x = ud.y * e1z, e2y = fm(ud.z, e1x, -(ud.x * e1z)), e2z = -(ud.y * e1x);
-        const R k1 = -fm(o.z, e1z, o.x * e1x);
-        const R k2 = -fm(o.z, e2z, fm(o.y, e2y, o.x * e2x));
-        const R t1x = time * e1x, t1z = time * e1z, t2x = time * e2x, t2y = time * e2y, t2z = time * e2z;
-        // one sphere: reject test in R (r² − p1² − p2² ≥ 0), candidates through the f64 quadratic
+        const Basis<R> basis = makeBasis<R>(ud, o);
         auto testSphere = [&](const Sph<R>& q) {
-            R p1 = fm(q.c.z, e1z, fm(q.c.x, e1x, k1));
-            if (q.v.x != R(0)) p1 = fm(q.v.x, t1x, p1);
-            if (q.v.z != R(0)) p1 = fm(q.v.z, t1z, p1);
-            R p2 = fm(q.c.z, e2z, fm(q.c.y, e2y, fm(q.c.x, e2x, k2)));
-            if (q.v.x != R(0)) p2 = fm(q.v.x, t2x, p2);
-            if (q.v.y != R(0)) p2 = fm(q.v.y, t2y, p2);
-            if (q.v.z != R(0)) p2 = fm(q.v.z, t2z, p2);
-            const R disc = fm(-p1, p1, fm(-p2, p2, q.r2)); // r² − dist²
-            if (!(disc >= R(0))) return;
-            // narrow phase: the reference's quadratic (src/geom.zig:40-58) in f64 on the f64 sphere, for the ray
-            // as the kernel holds it; the chosen root is rounded to R before the comparisons
-            double qx = q.c64[0] - (double)o.x, qy = q.c64[1] - (double)o.y, qz = q.c64[2] - (double)o.z;
-            qx = std::fma(q.v64[0], tm, qx);
-            qy = std::fma(q.v64[1], tm, qy);
-            qz = std::fma(q.v64[2], tm, qz);
-            const double hb2 = std::fma(dz, qz, std::fma(dy, qy, dx * qx));
-            const double cc2 = std::fma(qz, qz, std::fma(qy, qy, std::fma(qx, qx, -q.r2_64)));
-            const double disc2 = std::fma(-a2, cc2, hb2 * hb2);
-            if (!(disc2 >= 0.0)) return;
-            const double rt = std::sqrt(disc2);
-            const R t1 = (R)((hb2 - rt) * inv_a2), t2 = (R)((hb2 + rt) * inv_a2);
-            const R t = t1 >= tmin ? t1 : t2;
-            if (t >= tmin && (t < tbest || (t == tbest && (int)q.pool > ibest))) {
-                tbest = t;
-                ibest = (int)q.pool;
+            const R disc = sphereFilter<R>(basis, time, q.c, q.v, q.r2);
+            if (audit) {
+                R tb = inf;
+                int ib = -1;
+                const double disc2 = narrowRoots<R>(q.c64, q.v64, q.r2_64, o, d, time, tmin, (int)q.pool, tb, ib);
+                const R plain = (R)q.radius * (R)q.radius; // what the filter used before it was made conservative
+                audit->pairs++;
+                audit->candidates += disc >= R(0);
+                audit->f64_hits += disc2 >= 0.0;
+                audit->false_negatives += disc2 >= 0.0 && !(disc >= R(0));
+                audit->unpadded_false_negatives += disc2 >= 0.0 && !(sphereFilter<R>(basis, time, q.c, q.v, plain) >= R(0));
             }
+            if (!(disc >= R(0))) return;
+            narrowRoots<R>(q.c64, q.v64, q.r2_64, o, d, time, tmin, (int)q.pool, tbest, ibest);
         };
-        // one triangle (build-defined): Möller–Trumbore in R; sign-free barycentric filter, then t = (e2·q) / det
         const u32 n_sph = (u32)sc.sph.size();
         auto testTriangle = [&](const Tri<R>& q, u32 prim) {
-            const V<R> pv = cross3(d, q.e2);
-            const R det = dot3(q.e1, pv);
-            const V<R> sv{o.x - q.v0.x, o.y - q.v0.y, o.z - q.v0.z};
-            const R su = dot3(sv, pv) * det;
-            const V<R> qv = cross3(sv, q.e1);
-            const R svv = dot3(d, qv) * det;
-            const R w = fm(det, det, -(su + svv));
-            if (!(std::fmin(std::fmin(su, svv), w) >= R(0))) return;
-            if (det == R(0)) return;
-            const R t = dot3(q.e2, qv) / det;
-            if (t >= tmin && (t < tbest || (t == tbest && (int)prim > ibest))) {
-                tbest = t;
-                ibest = (int)prim;
-            }
+            triAccept<R>(triFilter<R>(q.v0, q.e1, q.e2, o, d), q.v0, q.e1, q.e2, o, d, tmin, (int)prim, tbest, ibest);
         };
         if (useBvh(p, (u32)(sc.sph.size() + sc.tri.size()))) {
-            // src/hit.zig:181-216 as a skip-link walk; slab test src/hit.zig:70-98 with 1/d hoisted and a
-            // 4-ulp slack (never culls a box the f64 narrow phase would hit)
+            // src/hit.zig:181-216 as a skip-link walk
             const V<R> inv{R(1) / d.x, R(1) / d.y, R(1) / d.z};
-            const R slack = R(1) + R(4) * std::numeric_limits<R>::epsilon();
             const u32 nn = (u32)sc.nodes.size();
             u32 idx = 0;
             while (idx < nn) {
                 const typename SceneB<R>::Node& nd = sc.nodes[idx];
                 res.node_tests++;
-                const R ax = (nd.lo[0] - o.x) * inv.x, bx = (nd.hi[0] - o.x) * inv.x;
-                const R ay = (nd.lo[1] - o.y) * inv.y, by = (nd.hi[1] - o.y) * inv.y;
-                const R az = (nd.lo[2] - o.z) * inv.z, bz = (nd.hi[2] - o.z) * inv.z;
-                const R t0 = std::fmax(std::fmax(std::fmin(ax, bx), std::fmin(ay, by)), std::fmax(std::fmin(az, bz), tmin));
-                const R t1 = std::fmin(std::fmin(std::fmax(ax, bx), std::fmax(ay, by)), std::fmin(std::fmax(az, bz), tbest));
+                R t0;
                 u32 next = nd.skip;
-                if (t1 * slack >= t0) {
+                if (boxHit<R>(nd.lo, nd.hi, inv, o, tmin, tbest, t0)) {
                     if (nd.count == 0) next = idx + 1;
                     for (u32 k = 0; k < nd.count; ++k) {
                         res.sphere_tests++;
@@ -940,84 +1122,28 @@ static PathResult<R> tracePath(const SceneB<R>& sc, const CamB<R>& cam, const Ra
             for (u32 i = 0; i < (u32)sc.tri.size(); ++i) testTriangle(sc.tri[i], n_sph + i);
         }
         if (ibest < 0) {                                                     // miss, src/renderer.zig:124-125
-            const R t = R(0.5) * (ud.y + R(1));
-            const R w = R(1) - t;
-            const V<R> col{(w + R(0.5)) * t, (w + R(0.7)) * t, (w + R(1.0)) * t};
+            const V<R> col = background<R>(ud);
             res.L = {thr.x * col.x, thr.y * col.y, thr.z * col.z};
             return res;
         }
-        // --- hit record, src/geom.zig:63-65 + src/hit.zig:25-41 ---
-        const V<R> pt{fm(d.x, tbest, o.x), fm(d.y, tbest, o.y), fm(d.z, tbest, o.z)};
-        V<R> nrm;
+        V<R> pt, nrm;
         u32 mat_idx;
         if ((u32)ibest < n_sph) {
             const Sph<R>& q = sc.sph[sc.by_pool[ibest]];
-            const V<R> cn{fm(q.v.x, time, q.c.x), fm(q.v.y, time, q.c.y), fm(q.v.z, time, q.c.z)};
-            nrm = unit(V<R>{pt.x - cn.x, pt.y - cn.y, pt.z - cn.z});
+            sphereHitRecord<R>(q.c, q.v, o, d, time, tbest, pt, nrm);
             mat_idx = q.mat;
         } else {
             const Tri<R>& q = sc.tri[(u32)ibest - n_sph];
+            pt = {fm(d.x, tbest, o.x), fm(d.y, tbest, o.y), fm(d.z, tbest, o.z)};
             nrm = unit(cross3(q.e1, q.e2));
             mat_idx = q.mat;
         }
-        const bool front = dot3(nrm, d) < R(0);
-        if (!front) nrm = neg(nrm);
+        const bool front = faceForward<R>(d, nrm);
 
         const Mat<R>& m = sc.mats[mat_idx];
-        V<R> nd, att;
-        if (m.kind == RAYZ_MAT_DIFFUSE) {                                    // src/material.zig:77-101
-            V<R> target;
-            if (m.method == RAYZ_DIFFUSE_HEMISPHERE) {
-                V<R> r = randomInUnitSphere(g);
-                if (!(dot3(r, nrm) > R(0))) r = neg(r);                      // :208-211
-                target = {pt.x + r.x, pt.y + r.y, pt.z + r.z};
-            } else {
-                V<R> r = randomInUnitSphere(g);
-                if (m.method == RAYZ_DIFFUSE_UNIT_SPHERE_SURFACE) r = unit(r);
-                target = {(pt.x + nrm.x) + r.x, (pt.y + nrm.y) + r.y, (pt.z + nrm.z) + r.z};
-            }
-            const R tol = (R)1e-8;
-            if (std::fabs(target.x) <= tol && std::fabs(target.y) <= tol && std::fabs(target.z) <= tol)
-                target = nrm;                                                // :85-86 (tests the POINT; preserved)
-            nd = {target.x - pt.x, target.y - pt.y, target.z - pt.z};
-            att = textureValue(sc, m.texture, pt);
-        } else if (m.kind == RAYZ_MAT_METALLIC) {                            // :108-131
-            const R k = R(2) * dot3(d, nrm);
-            V<R> r = unit(V<R>{fm(-k, nrm.x, d.x), fm(-k, nrm.y, d.y), fm(-k, nrm.z, d.z)});
-            if (m.param > R(0)) {
-                const V<R> ru = unit(randomInUnitSphere(g));
-                const R f = m.param < R(1) ? m.param : R(1);
-                r = {fm(ru.x, f, r.x), fm(ru.y, f, r.y), fm(ru.z, f, r.z)};
-            }
-            if (dot3(r, nrm) <= R(0)) return res;                            // absorbed → black
-            nd = r;
-            att = textureValue(sc, m.texture, pt);
-        } else {                                                             // :137-159
-            const R eta = front ? m.inv_param : m.param;
-            const R cosv = -dot3(ud, nrm);
-            const R sinv = std::sqrt(fm(-cosv, cosv, R(1)));
-            bool refl = eta * sinv > R(1);
-            if (!refl) {
-                R r0 = (R(1) - eta) / (R(1) + eta);                          // :179-183, pow(x,5) → x²·x²·x
-                r0 = r0 * r0;
-                const R xx = R(1) - cosv;
-                const R x2 = xx * xx;
-                const R x5 = (x2 * x2) * xx;
-                const R rf = fm(R(1) - r0, x5, r0);
-                refl = rf > g.uniform();
-            }
-            if (refl) {
-                const R k = R(2) * dot3(d, nrm);                             // :185-187, unnormalised d
-                nd = {fm(-k, nrm.x, d.x), fm(-k, nrm.y, d.y), fm(-k, nrm.z, d.z)};
-            } else {                                                         // :189-194
-                const V<R> perp{fm(nrm.x, cosv, ud.x) * eta, fm(nrm.y, cosv, ud.y) * eta,
-                                fm(nrm.z, cosv, ud.z) * eta};
-                // clamped at 0: see DESIGN.md §4.5 (f32 rounds 1 − |perp|² below 0 near the critical angle)
-                const R sp = -std::sqrt(std::fmax(R(1) - dot3(perp, perp), R(0)));
-                nd = {fm(nrm.x, sp, perp.x), fm(nrm.y, sp, perp.y), fm(nrm.z, sp, perp.z)};
-            }
-            att = {1, 1, 1};
-        }
+        V<R> nd;
+        if (!scatterDir<R>(m.kind, m.method, m.param, m.inv_param, g, d, ud, pt, nrm, front, nd)) return res; // absorbed
+        const V<R> att = m.kind == RAYZ_MAT_DIELECTRIC ? V<R>{1, 1, 1} : textureValue(sc, m.texture, pt);
         thr = {thr.x * att.x, thr.y * att.y, thr.z * att.z};
         o = pt;
         d = nd;
@@ -1043,7 +1169,7 @@ static int render(const RayzSceneDesc* sd, const RayzCameraDesc* cd, const RayzR
     if (!sd || !cd || !pp || !out) return RAYZ_ERR_BAD_ARG;
     const RayzRenderParams p = *pp;
     if (!p.width || !p.height || !p.samples_per_px) return RAYZ_ERR_BAD_ARG;
-    SceneB<R> sc = buildScene<R>(*sd);
+    SceneB<R> sc = buildScene<R>(*sd, originBound(*sd, cd));
     if (useBvh(*pp, sd->n_spheres + sd->n_triangles)) buildBvh<R>(*sd, sc);
     const CamB<R> cam = buildCamera<R>(*cd);
     const u32 C = p.chunk_spp ? p.chunk_spp : 16;
@@ -1138,6 +1264,221 @@ int rayz_oracle_render_b_f64(const RayzSceneDesc* s, const RayzCameraDesc* c, co
 }
 uint32_t rayz_oracle_shard_rows(const RayzRenderParams* p) { return B::shardRows(*p, nullptr); }
 
+// ---- known answers: the pieces of mode B (kernel arithmetic) and of mode A (the reference as written) on the record
+// formats of rayz_hip_kat (include/rayz_hip.h: RayzKatOp, RAYZ_KAT_IN_STRIDE / RAYZ_KAT_OUT_STRIDE) ---------------------
+} // extern "C"
+namespace {
+template <class R> static void katB(uint32_t op, const double* a, double* r) {
+    using namespace B;
+    auto v3 = [&](int k) { return V<R>{(R)a[k], (R)a[k + 1], (R)a[k + 2]}; };
+    auto put3 = [&](int k, V<R> v) { r[k] = (double)v.x, r[k + 1] = (double)v.y, r[k + 2] = (double)v.z; };
+    switch (op) {
+    case RAYZ_KAT_REFRACT: {
+        const V<R> ud = v3(0), nrm = v3(3);
+        put3(0, refract<R>(ud, nrm, -dot3(ud, nrm), (R)a[6]));
+        break;
+    }
+    case RAYZ_KAT_REFLECTANCE: r[0] = (double)reflectance<R>((R)a[0], (R)a[1]); break;
+    case RAYZ_KAT_GET_RAY: {
+        CamB<R> cam;
+        cam.from = v3(0), cam.du = v3(3), cam.dv = v3(6), cam.pxo = v3(9), cam.defu = v3(12), cam.defv = v3(15);
+        cam.defocus = a[18] != 0.0;
+        ListRng<R> g{a + 22, (u32)a[21], 0u};
+        V<R> o, d;
+        R time;
+        cameraRay<R>(cam, g, (u32)a[19], (u32)a[20], o, d, time);
+        put3(0, o);
+        put3(3, d);
+        r[6] = (double)time;
+        r[7] = (double)g.i;
+        break;
+    }
+    case RAYZ_KAT_BOX_HIT: {
+        const V<R> d = v3(9);
+        const V<R> inv{R(1) / d.x, R(1) / d.y, R(1) / d.z};
+        const R lo[3] = {(R)a[0], (R)a[1], (R)a[2]}, hi[3] = {(R)a[3], (R)a[4], (R)a[5]};
+        R t0;
+        r[0] = boxHit<R>(lo, hi, inv, v3(6), (R)a[12], (R)a[13], t0) ? 1.0 : 0.0;
+        r[1] = (double)t0;
+        break;
+    }
+    case RAYZ_KAT_SPHERE_HIT: {
+        RayzSphere q{};
+        for (int k = 0; k < 3; ++k) q.center[k] = a[k], q.velocity[k] = a[3 + k];
+        q.radius = a[6];
+        const V<R> o = v3(7), d = v3(10);
+        const R time = (R)a[13], tmin = (R)a[14];
+        const double S = std::max(norm3(a + 7), norm3(q.center) + norm3(q.velocity) + std::fabs(q.radius));
+        const V<R> c = v3(0), v = v3(3);
+        const Basis<R> b = makeBasis<R>(unit(d), o);
+        const bool cand = sphereFilter<R>(b, time, c, v, padRadius2<R>(q, S)) >= R(0);
+        r[9] = cand ? 1.0 : 0.0;
+        R tbest = (R)a[15];
+        int ibest = -1;
+        if (cand) narrowRoots<R>(q.center, q.velocity, q.radius * q.radius, o, d, time, tmin, 1, tbest, ibest);
+        if (ibest >= 0) {
+            V<R> pt, nrm;
+            sphereHitRecord<R>(c, v, o, d, time, tbest, pt, nrm);
+            const bool front = faceForward<R>(d, nrm);
+            r[0] = 1.0, r[1] = (double)tbest;
+            put3(2, pt);
+            put3(5, nrm);
+            r[8] = front ? 1.0 : 0.0;
+        }
+        break;
+    }
+    case RAYZ_KAT_SCATTER: {
+        const R param = (R)a[2];
+        const V<R> d = v3(6);
+        ListRng<R> g{a + 17, (u32)a[16], 0u};
+        V<R> nd{0, 0, 0};
+        const bool ok = scatterDir<R>((u32)a[0], (u32)a[1], param, R(1) / param, g, d, unit(d), v3(9), v3(12), a[15] != 0.0, nd);
+        r[0] = ok ? 1.0 : 0.0;
+        put3(1, nd);
+        r[4] = (double)g.i;
+        break;
+    }
+    case RAYZ_KAT_CHECKER: r[0] = (double)checkerParity<R>(v3(0), (R)a[3]); break;
+    case RAYZ_KAT_BACKGROUND: put3(0, background<R>(unit(v3(0)))); break;
+    case RAYZ_KAT_TRIANGLE_HIT: {
+        const V<R> v0 = v3(0), o = v3(9), d = v3(12);
+        const V<R> e1{(R)(a[3] - a[0]), (R)(a[4] - a[1]), (R)(a[5] - a[2])}, e2{(R)(a[6] - a[0]), (R)(a[7] - a[1]), (R)(a[8] - a[2])};
+        const R f = triFilter<R>(v0, e1, e2, o, d);
+        R tbest = (R)a[16];
+        int ibest = -1;
+        triAccept<R>(f, v0, e1, e2, o, d, (R)a[15], 1, tbest, ibest);
+        r[0] = ibest >= 0 ? 1.0 : 0.0;
+        r[1] = ibest >= 0 ? (double)tbest : 0.0;
+        r[2] = f >= R(0) ? 1.0 : 0.0;
+        break;
+    }
+    default: break;
+    }
+}
+
+// The same records through the reference's own functions (mode A, f64, literal operation order).
+static void katA(uint32_t op, const double* a, double* r) {
+    using namespace A;
+    auto put3 = [&](int k, V3 v) { r[k] = v.x, r[k + 1] = v.y, r[k + 2] = v.z; };
+    switch (op) {
+    case RAYZ_KAT_REFRACT: put3(0, refract(v3(a), v3(a + 3), a[6])); break;
+    case RAYZ_KAT_REFLECTANCE: r[0] = reflectance(a[0], a[1]); break;
+    case RAYZ_KAT_GET_RAY: {
+        Camera c;
+        c.look_from = v3(a), c.px_du = v3(a + 3), c.px_dv = v3(a + 6), c.px_origin = v3(a + 9);
+        c.defocus_u = v3(a + 12), c.defocus_v = v3(a + 15);
+        c.defocus = a[18] != 0.0;
+        A::ListRng g{a + 22, (u32)a[21], 0u};
+        const Ray ray = c.getRay((size_t)a[19], (size_t)a[20], &g);
+        put3(0, ray.origin);
+        put3(3, ray.dir);
+        r[6] = ray.time;
+        r[7] = (double)g.i;
+        break;
+    }
+    case RAYZ_KAT_BOX_HIT: {
+        Ray ray;
+        ray.origin = v3(a + 6), ray.dir = v3(a + 9);
+        r[0] = AABB{v3(a), v3(a + 3)}.hit(ray, a[12], a[13]) ? 1.0 : 0.0;
+        break;
+    }
+    case RAYZ_KAT_SPHERE_HIT: {
+        Sphere q;
+        q.center.origin = v3(a), q.center.dir = v3(a + 3);
+        q.radius = a[6];
+        q.material = 0;
+        Ray ray;
+        ray.origin = v3(a + 7), ray.dir = v3(a + 10), ray.time = a[13];
+        const Hit h = q.hitInner(ray, a[14], a[15]);
+        if (h.valid) {
+            r[0] = 1.0, r[1] = h.t;
+            put3(2, h.point);
+            put3(5, h.normal);
+            r[8] = h.front_face ? 1.0 : 0.0;
+        }
+        r[9] = r[0];
+        break;
+    }
+    case RAYZ_KAT_SCATTER: {
+        Scene sc;
+        RayzTexture white{};
+        white.kind = RAYZ_TEX_SOLID;
+        white.color[0] = white.color[1] = white.color[2] = 1.0;
+        sc.textures.push_back(white);
+        RayzMaterial m{};
+        m.kind = (u32)a[0], m.method = (u32)a[1], m.param = a[2], m.texture = 0;
+        Ray ray;
+        ray.origin = v3(a + 3), ray.dir = v3(a + 6);
+        Hit h;
+        h.point = v3(a + 9), h.normal = v3(a + 12), h.front_face = a[15] != 0.0, h.valid = true;
+        A::ListRng g{a + 17, (u32)a[16], 0u};
+        const Scatter sct = scatter(sc, m, g, ray, h);
+        r[0] = sct.ok ? 1.0 : 0.0;
+        if (sct.ok) put3(1, sct.ray.dir);
+        r[4] = (double)g.i;
+        break;
+    }
+    case RAYZ_KAT_CHECKER: r[0] = (double)checkerParity(v3(a), a[3]); break;
+    case RAYZ_KAT_BACKGROUND: put3(0, background(v3(a))); break;
+    case RAYZ_KAT_TRIANGLE_HIT: {
+        Triangle t{v3(a), v3(a + 3), v3(a + 6), 0};
+        Ray ray;
+        ray.origin = v3(a + 9), ray.dir = v3(a + 12);
+        const Hit h = t.hitInner(ray, a[15], a[16]);
+        r[0] = h.valid ? 1.0 : 0.0;
+        r[1] = h.valid ? h.t : 0.0;
+        r[2] = r[0];
+        break;
+    }
+    default: break;
+    }
+}
+} // namespace
+extern "C" {
+
+int rayz_oracle_kat_b(uint32_t op, uint32_t precision, const double* in, uint32_t n, double* out) {
+    if (op > RAYZ_KAT_TRIANGLE_HIT || precision > RAYZ_PRECISION_F64 || (n && (!in || !out))) return RAYZ_ERR_BAD_ARG;
+    for (uint32_t i = 0; i < n; ++i) {
+        double* r = out + (size_t)i * RAYZ_KAT_OUT_STRIDE;
+        std::fill(r, r + RAYZ_KAT_OUT_STRIDE, 0.0);
+        if (precision == RAYZ_PRECISION_F32) katB<float>(op, in + (size_t)i * RAYZ_KAT_IN_STRIDE, r);
+        else katB<double>(op, in + (size_t)i * RAYZ_KAT_IN_STRIDE, r);
+    }
+    return RAYZ_OK;
+}
+int rayz_oracle_kat_a(uint32_t op, const double* in, uint32_t n, double* out) {
+    if (op > RAYZ_KAT_TRIANGLE_HIT || (n && (!in || !out))) return RAYZ_ERR_BAD_ARG;
+    for (uint32_t i = 0; i < n; ++i) {
+        double* r = out + (size_t)i * RAYZ_KAT_OUT_STRIDE;
+        std::fill(r, r + RAYZ_KAT_OUT_STRIDE, 0.0);
+        katA(op, in + (size_t)i * RAYZ_KAT_IN_STRIDE, r);
+    }
+    return RAYZ_OK;
+}
+
+// Flat-list replay of the listed pixels that checks the reject filter against the f64 discriminant for EVERY
+// (segment, sphere) pair: out[0..4] = pairs, candidates, f64 hits, false negatives, false negatives of the unpadded
+// filter (what the kernel used before the filter was made conservative).
+int rayz_oracle_filter_audit(const RayzSceneDesc* sd, const RayzCameraDesc* cd, const RayzRenderParams* pp, uint32_t precision,
+                             const uint32_t* pixel_list, uint32_t n_list, uint64_t* out) {
+    if (!sd || !cd || !pp || !out || (n_list && !pixel_list)) return RAYZ_ERR_BAD_ARG;
+    RayzRenderParams p = *pp;
+    p.traversal = RAYZ_TRAVERSAL_LINEAR;
+    B::FilterAudit au;
+    auto run = [&](auto tag) {
+        typedef decltype(tag) R;
+        const B::SceneB<R> sc = B::buildScene<R>(*sd, B::originBound(*sd, cd));
+        const B::CamB<R> cam = B::buildCamera<R>(*cd);
+        for (uint32_t k = 0; k < n_list; ++k)
+            for (uint32_t s = 0; s < p.samples_per_px; ++s)
+                B::tracePath<R>(sc, cam, p, pixel_list[k] % p.width, pixel_list[k] / p.width, s, &au);
+    };
+    if (precision == RAYZ_PRECISION_F32) run(float{});
+    else run(double{});
+    out[0] = au.pairs, out[1] = au.candidates, out[2] = au.f64_hits, out[3] = au.false_negatives, out[4] = au.unpadded_false_negatives;
+    return RAYZ_OK;
+}
+
 // ---- mode A: `Tracer.render` over rows [row_begin,row_end) with ONE sequential stream ----
 // rng_state: 4 u64 in/out (the Tracer's DefaultPrng, continued from scene generation, src/rayz.zig:109).
 // out: (row_end-row_begin)*width*3 doubles; sumsq (optional) receives per-pixel Σ L² per channel.
@@ -1217,7 +1558,7 @@ void rayz_oracle_camera_init(double vfov, double focus_dist, double defocus_angl
                 out);
 }
 void rayz_oracle_get_ray_norng(const RayzCameraDesc* c, uint32_t px, uint32_t py, double* origin, double* dir) {
-    const A::Ray r = A::cameraFrom(*c).getRay(px, py, nullptr);
+    const A::Ray r = A::cameraFrom(*c).getRay<Xoshiro256pp>(px, py, nullptr);
     origin[0] = r.origin.x, origin[1] = r.origin.y, origin[2] = r.origin.z;
     dir[0] = r.dir.x, dir[1] = r.dir.y, dir[2] = r.dir.z;
 }

@@ -15,6 +15,9 @@ LIB_PATH = os.path.join(HERE, "csrc", "librayz_hip.so")
 ABI_VERSION = 4
 MAX_DEVICES = 64
 GATHER_RCCL, GATHER_PEER_COPY = 0, 1
+(KAT_REFRACT, KAT_REFLECTANCE, KAT_GET_RAY, KAT_BOX_HIT, KAT_SPHERE_HIT, KAT_SCATTER, KAT_CHECKER, KAT_BACKGROUND,
+ KAT_TRIANGLE_HIT) = range(9)
+KAT_IN_STRIDE, KAT_OUT_STRIDE = 48, 12
 
 OK = 0
 ERR_BAD_ARG = -1
@@ -104,6 +107,7 @@ PROTOTYPES = [
      [C.POINTER(SceneDesc), C.POINTER(CameraDesc), C.POINTER(RenderParams), C.c_void_p,
       C.POINTER(RenderStats)]),
     ("rayz_hip_tonemap_u8", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    ("rayz_hip_kat", C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(C.c_double), C.c_uint32, C.POINTER(C.c_double)]),
     ("rayz_hip_multi_create", C.c_int,
      [C.POINTER(C.c_int), C.c_int, C.POINTER(SceneDesc), C.c_uint32, C.POINTER(C.c_void_p)]),
     ("rayz_hip_multi_destroy", C.c_int, [C.c_void_p]),

@@ -154,8 +154,19 @@ struct Pcg32 {
 template <class R> __device__ __forceinline__ R uniform(Pcg32& g);
 template <> __device__ __forceinline__ float uniform<float>(Pcg32& g) { return (float)(g.next() >> 8) * 0x1p-24f; }
 template <> __device__ __forceinline__ double uniform<double>(Pcg32& g) { return (double)g.next() * 0x1p-32; }
+// Known-answer entry (rayz_hip_kat) only: draws come from a caller-supplied list, so that the device functions can
+// be evaluated on the same uniforms as the reference restatement (0.5 once the list is used up).
+struct ListRng {
+    const double* u;
+    uint32_t n, i;
+};
+template <class R> __device__ __forceinline__ R uniform(ListRng& g) {
+    const R v = g.i < g.n ? (R)g.u[g.i] : R(0.5);
+    g.i++;
+    return v;
+}
 
-template <class R> __device__ __forceinline__ V<R> random_in_unit_sphere(Pcg32& g) { // src/material.zig:196-202
+template <class R, class G> __device__ __forceinline__ V<R> random_in_unit_sphere(G& g) { // src/material.zig:196-202
     V<R> v{0, 0, 0};
     for (int i = 0; i < kMaxRejectionTries; ++i) {
         v.x = fm(uniform<R>(g), R(2), R(-1));
@@ -166,26 +177,30 @@ template <class R> __device__ __forceinline__ V<R> random_in_unit_sphere(Pcg32& 
     return v;
 }
 
+// Cell parity of a checker at point p: floor(p_k / scale) summed as integers, floored mod 2 (src/material.zig:32-36;
+// the reference sums i64s, here each floor is clamped to ±2^30 and summed as int32 — same parity inside that range).
+template <class R> __device__ __forceinline__ uint32_t checker_parity(V<R> p, R scale) {
+    const R lim = R(1073741824.0);
+    R fx = fl(p.x / scale), fy = fl(p.y / scale), fz = fl(p.z / scale);
+    fx = fx < -lim ? -lim : fx;
+    fx = fx > lim ? lim : fx;
+    fy = fy < -lim ? -lim : fy;
+    fy = fy > lim ? lim : fy;
+    fz = fz < -lim ? -lim : fz;
+    fz = fz > lim ? lim : fz;
+    const uint32_t s = (uint32_t)(int32_t)fx + (uint32_t)(int32_t)fy + (uint32_t)(int32_t)fz;
+    return s & 1u;
+}
 template <class R>
 __device__ __forceinline__ V<R> texture_value(const DevScene<R>& sc, uint32_t idx, V<R> p) { // src/material.zig:19-51
     typedef typename VecOf<R>::type r4;
-    for (int depth = 0; depth < kMaxTextureDepth; ++depth) {
+    for (int depth = 0; depth < kMaxTextureDepth; ++depth) { // rayz_hip_scene_create refuses deeper chains and cycles
         const r4 h = sc.tex[2 * idx];
         if (bits(h.x) == 1u) { // RAYZ_TEX_SOLID
             const r4 c = sc.tex[2 * idx + 1];
             return {c.x, c.y, c.z};
         }
-        const R scale = h.w;
-        const R lim = R(1073741824.0);
-        R fx = fl(p.x / scale), fy = fl(p.y / scale), fz = fl(p.z / scale);
-        fx = fx < -lim ? -lim : fx;
-        fx = fx > lim ? lim : fx;
-        fy = fy < -lim ? -lim : fy;
-        fy = fy > lim ? lim : fy;
-        fz = fz < -lim ? -lim : fz;
-        fz = fz > lim ? lim : fz;
-        const uint32_t s = (uint32_t)(int32_t)fx + (uint32_t)(int32_t)fy + (uint32_t)(int32_t)fz;
-        idx = (s & 1u) == 0u ? bits(h.y) : bits(h.z);
+        idx = checker_parity<R>(p, h.w) == 0u ? bits(h.y) : bits(h.z);
     }
     return {R(0), R(0), R(0)};
 }
@@ -231,7 +246,7 @@ template <class R> __device__ __forceinline__ RayBasis<R> make_basis(V<R> ud, V<
     const R h2 = fm(ud.z, ud.z, ud.x * ud.x);
     b.e1x = R(1);
     b.e1z = R(0);
-    if (h2 > R(0)) {
+    if (h2 > R(1e-30)) { // below that (|ud.x|, |ud.z| < 1e-15) the x axis is perpendicular to ud far inside the slack
         const R ih = R(1) / sq(h2);
         b.e1x = ud.z * ih;
         b.e1z = -(ud.x * ih);
@@ -250,6 +265,13 @@ template <class R> __device__ __forceinline__ R basis_p2(const RayBasis<R>& b, R
     return fm(cz, b.e2z, fm(cy, b.e2y, fm(cx, b.e2x, b.k2)));
 }
 template <class R> __device__ __forceinline__ R basis_disc(R p1, R p2, R r2) { return fm(-p1, p1, fm(-p2, p2, r2)); }
+// The filter is CONSERVATIVE: `r2` is not r² but (r + E)², E = 32·u·(|c| + |v| + r + S) added on the host
+// (pad_radius2 in rayz_hip.hip; u = unit roundoff of R, S = bound on every ray origin).  E covers the rounding of
+// unit(d), of the basis, of k, p1, p2 and of this expression (derivation: DESIGN.md §4.3), so a sphere whose f64
+// discriminant is ≥ 0 always reaches the narrow phase; the narrow phase decides.
+template <class R> __device__ __forceinline__ bool sphere_candidate(R p1, R p2, R r2_padded) {
+    return basis_disc<R>(p1, p2, r2_padded) >= R(0);
+}
 
 template <class R, int N> __device__ __forceinline__ R max_of(const R (&v)[N]) {
     R m = v[0];
@@ -266,7 +288,8 @@ __device__ __forceinline__ double mn(double a, double b) { return __builtin_fmin
 
 // ---- build-defined triangle (Möller–Trumbore in R) ----------------------------------
 // Filter value: ≥ 0 iff the barycentrics pass, written without a division or a sign branch:
-// su = (s·p)·det, sv = (d·q)·det, w = det² − (su + sv); candidate iff min(su, sv, w) ≥ 0.
+// su = (s·p)·det, sv = (d·q)·det, w = det² − (su + sv); candidate iff min(su, sv, w) ≥ 0.  There is no f64 phase
+// behind it: for triangles this value IS the decision (in R, identically in the oracle), not a pre-filter.
 template <class R> __device__ __forceinline__ R tri_filter(V<R> v0, V<R> e1, V<R> e2, V<R> o, V<R> d) {
     const V<R> pv = cross3(d, e2);
     const R det = dot3(e1, pv);
@@ -582,45 +605,55 @@ template <class R, int NR> __device__ __forceinline__ void scan_spheres(const De
     scan_triangles<R, NR>(sc, ray, tmin);
 }
 
-// ---- shading of one segment: returns false when the path ends ------------------------------------
-// On a miss adds thr ⊙ background to acc (src/renderer.zig:124-125); on absorption adds nothing.
-// `ibest` is a POOL index; `ud` = unit(d) as the scan used it.
+// ---- pieces of the shading step; the trace kernels use them through shade(), the known-answer entry calls them
+// directly (the same instructions either way) ------------------------------------------------------------------------
+// Background of a ray that hits nothing: ((1−t)·(1,1,1) + (0.5,0.7,1.0))·t, t = ½(unit(d).y + 1) — not a lerp,
+// src/renderer.zig:124-125.
+template <class R> __device__ __forceinline__ V<R> background(V<R> ud) {
+    const R t = R(0.5) * (ud.y + R(1));
+    const R w = R(1) - t;
+    return {(w + R(0.5)) * t, (w + R(0.7)) * t, (w + R(1.0)) * t};
+}
+// Hit point, outward normal of a (moving) sphere and the front-face flip: src/geom.zig:63-65, src/hit.zig:25-41.
 template <class R>
-__device__ __forceinline__ bool shade(const DevScene<R>& sc, Pcg32& g, V<R>& o, V<R>& d, V<R> ud, R time, R tbest,
-                                      int ibest, V<R>& thr, V<R>& acc) {
-    typedef typename VecOf<R>::type r4;
-    if (ibest < 0) {
-        const R t = R(0.5) * (ud.y + R(1));
-        const R w = R(1) - t;
-        const V<R> col{(w + R(0.5)) * t, (w + R(0.7)) * t, (w + R(1.0)) * t};
-        acc.x = acc.x + thr.x * col.x;
-        acc.y = acc.y + thr.y * col.y;
-        acc.z = acc.z + thr.z * col.z;
-        return false;
-    }
-    // hit record: src/geom.zig:63-65, src/hit.zig:25-41 (spheres); geometric normal for triangles
-    const V<R> pt{fm(d.x, tbest, o.x), fm(d.y, tbest, o.y), fm(d.z, tbest, o.z)};
-    V<R> nrm;
-    uint32_t mat_idx;
-    if ((uint32_t)ibest < sc.n_spheres) {
-        const r4 q = sc.sph_pool[2 * ibest], w4 = sc.sph_pool[2 * ibest + 1];
-        const V<R> cn{fm(w4.x, time, q.x), fm(w4.y, time, q.y), fm(w4.z, time, q.z)};
-        nrm = unit(V<R>{pt.x - cn.x, pt.y - cn.y, pt.z - cn.z});
-        mat_idx = bits(w4.w);
-    } else {
-        const uint32_t ti = (uint32_t)ibest - sc.n_spheres;
-        const r4 a = sc.tri[3 * ti], b = sc.tri[3 * ti + 1], c = sc.tri[3 * ti + 2];
-        nrm = unit(cross3(V<R>{b.x, b.y, b.z}, V<R>{c.x, c.y, c.z}));
-        mat_idx = bits(a.w);
-    }
+__device__ __forceinline__ void sphere_hit_record(typename VecOf<R>::type c, typename VecOf<R>::type v, V<R> o, V<R> d, R time,
+                                                  R t, V<R>& pt, V<R>& nrm) {
+    pt = {fm(d.x, t, o.x), fm(d.y, t, o.y), fm(d.z, t, o.z)};
+    const V<R> cn{fm(v.x, time, c.x), fm(v.y, time, c.y), fm(v.z, time, c.z)};
+    nrm = unit(V<R>{pt.x - cn.x, pt.y - cn.y, pt.z - cn.z});
+}
+template <class R> __device__ __forceinline__ bool face_forward(V<R> d, V<R>& nrm) { // Hit.init, src/hit.zig:33-36
     const bool front = dot3(nrm, d) < R(0);
     if (!front) nrm = neg(nrm);
-
-    const r4 m = sc.mat[mat_idx];
-    const uint32_t kind = bits(m.x) & 0xffu, method = (bits(m.x) >> 8) & 0xffu, texture = bits(m.y);
-    const R param = m.z, inv_param = m.w;
-    V<R> nd, att;
-    if (kind == 0u) { // diffuse, src/material.zig:77-101
+    return front;
+}
+// Schlick's reflectance with pow(x, 5) as multiplies: src/material.zig:179-183.
+template <class R> __device__ __forceinline__ R reflectance(R cosv, R eta) {
+    R r0 = (R(1) - eta) / (R(1) + eta);
+    r0 = r0 * r0;
+    const R xx = R(1) - cosv;
+    const R x2 = xx * xx;
+    const R x5 = (x2 * x2) * xx;
+    return fm(R(1) - r0, x5, r0);
+}
+template <class R> __device__ __forceinline__ V<R> reflect(V<R> d, V<R> nrm) { // src/material.zig:185-187
+    const R k = R(2) * dot3(d, nrm);
+    return {fm(-k, nrm.x, d.x), fm(-k, nrm.y, d.y), fm(-k, nrm.z, d.z)};
+}
+// src/material.zig:189-194 with cos = −ud·n handed in (the caller has it).  Exact arithmetic has 1 − |perp|² ≥ 0
+// here (eta·sin ≤ 1); in f32 it rounds below 0 about once per 1e9 samples and the reference's bare sqrt (:192)
+// would make the pixel NaN: clamped at 0.
+template <class R> __device__ __forceinline__ V<R> refract(V<R> ud, V<R> nrm, R cosv, R eta) {
+    const V<R> perp{fm(nrm.x, cosv, ud.x) * eta, fm(nrm.y, cosv, ud.y) * eta, fm(nrm.z, cosv, ud.z) * eta};
+    const R sp = -sq(mx(R(1) - dot3(perp, perp), R(0)));
+    return {fm(nrm.x, sp, perp.x), fm(nrm.y, sp, perp.y), fm(nrm.z, sp, perp.z)};
+}
+// `Material.scatter` (src/material.zig:73-160) without the texture lookup: the scattered direction, or false when
+// a metal absorbs the ray.  `d` is the incoming direction as the ray holds it (unnormalised), `ud` = unit(d).
+template <class R, class G>
+__device__ __forceinline__ bool scatter_dir(uint32_t kind, uint32_t method, R param, R inv_param, G& g, V<R> d, V<R> ud, V<R> pt,
+                                            V<R> nrm, bool front, V<R>& nd) {
+    if (kind == 0u) { // diffuse, :77-101
         V<R> target;
         V<R> r = random_in_unit_sphere<R>(g);
         if (method == 2u) { // HEMISPHERE, :208-211
@@ -633,10 +666,8 @@ __device__ __forceinline__ bool shade(const DevScene<R>& sc, Pcg32& g, V<R>& o, 
         const R tol = (R)1e-8;
         if (ab(target.x) <= tol && ab(target.y) <= tol && ab(target.z) <= tol) target = nrm; // :85-86
         nd = {target.x - pt.x, target.y - pt.y, target.z - pt.z};
-        att = texture_value<R>(sc, texture, pt);
     } else if (kind == 1u) { // metallic, :108-131
-        const R k = R(2) * dot3(d, nrm);
-        V<R> r = unit(V<R>{fm(-k, nrm.x, d.x), fm(-k, nrm.y, d.y), fm(-k, nrm.z, d.z)});
+        V<R> r = unit(reflect<R>(d, nrm));
         if (param > R(0)) {
             const V<R> ru = unit(random_in_unit_sphere<R>(g));
             const R f = param < R(1) ? param : R(1);
@@ -644,33 +675,52 @@ __device__ __forceinline__ bool shade(const DevScene<R>& sc, Pcg32& g, V<R>& o, 
         }
         if (dot3(r, nrm) <= R(0)) return false; // absorbed
         nd = r;
-        att = texture_value<R>(sc, texture, pt);
     } else { // dielectric, :137-159
         const R eta = front ? inv_param : param;
         const R cosv = -dot3(ud, nrm);
         const R sinv = sq(fm(-cosv, cosv, R(1)));
         bool refl = eta * sinv > R(1);
-        if (!refl) { // the draw happens only when not totally internally reflecting, :145
-            R r0 = (R(1) - eta) / (R(1) + eta);
-            r0 = r0 * r0;
-            const R xx = R(1) - cosv;
-            const R x2 = xx * xx;
-            const R x5 = (x2 * x2) * xx;
-            const R rf = fm(R(1) - r0, x5, r0);
-            refl = rf > uniform<R>(g);
-        }
-        if (refl) {
-            const R k = R(2) * dot3(d, nrm);
-            nd = {fm(-k, nrm.x, d.x), fm(-k, nrm.y, d.y), fm(-k, nrm.z, d.z)};
-        } else {
-            const V<R> perp{fm(nrm.x, cosv, ud.x) * eta, fm(nrm.y, cosv, ud.y) * eta, fm(nrm.z, cosv, ud.z) * eta};
-            // exact arithmetic has 1 − |perp|² ≥ 0 here (eta·sin ≤ 1); in f32 it rounds below 0 about once per 1e9
-            // samples and the reference's bare sqrt (src/material.zig:192) would make the pixel NaN: clamp at 0
-            const R sp = -sq(mx(R(1) - dot3(perp, perp), R(0)));
-            nd = {fm(nrm.x, sp, perp.x), fm(nrm.y, sp, perp.y), fm(nrm.z, sp, perp.z)};
-        }
-        att = {R(1), R(1), R(1)};
+        if (!refl) refl = reflectance<R>(cosv, eta) > uniform<R>(g); // the draw happens only when not TIR, :145
+        nd = refl ? reflect<R>(d, nrm) : refract<R>(ud, nrm, cosv, eta);
     }
+    return true;
+}
+
+// ---- shading of one segment: returns false when the path ends ------------------------------------
+// On a miss adds thr ⊙ background to acc (src/renderer.zig:124-125); on absorption adds nothing.
+// `ibest` is a POOL index; `ud` = unit(d) as the scan used it.
+template <class R>
+__device__ __forceinline__ bool shade(const DevScene<R>& sc, Pcg32& g, V<R>& o, V<R>& d, V<R> ud, R time, R tbest,
+                                      int ibest, V<R>& thr, V<R>& acc) {
+    typedef typename VecOf<R>::type r4;
+    if (ibest < 0) {
+        const V<R> col = background<R>(ud);
+        acc.x = acc.x + thr.x * col.x;
+        acc.y = acc.y + thr.y * col.y;
+        acc.z = acc.z + thr.z * col.z;
+        return false;
+    }
+    // hit record: src/geom.zig:63-65, src/hit.zig:25-41 (spheres); geometric normal for triangles
+    V<R> pt, nrm;
+    uint32_t mat_idx;
+    if ((uint32_t)ibest < sc.n_spheres) {
+        const r4 q = sc.sph_pool[2 * ibest], w4 = sc.sph_pool[2 * ibest + 1];
+        sphere_hit_record<R>(q, w4, o, d, time, tbest, pt, nrm);
+        mat_idx = bits(w4.w);
+    } else {
+        const uint32_t ti = (uint32_t)ibest - sc.n_spheres;
+        const r4 a = sc.tri[3 * ti], b = sc.tri[3 * ti + 1], c = sc.tri[3 * ti + 2];
+        pt = {fm(d.x, tbest, o.x), fm(d.y, tbest, o.y), fm(d.z, tbest, o.z)};
+        nrm = unit(cross3(V<R>{b.x, b.y, b.z}, V<R>{c.x, c.y, c.z}));
+        mat_idx = bits(a.w);
+    }
+    const bool front = face_forward<R>(d, nrm);
+
+    const r4 m = sc.mat[mat_idx];
+    const uint32_t kind = bits(m.x) & 0xffu, method = (bits(m.x) >> 8) & 0xffu, texture = bits(m.y);
+    V<R> nd;
+    if (!scatter_dir<R>(kind, method, m.z, m.w, g, d, ud, pt, nrm, front, nd)) return false;
+    const V<R> att = kind == 2u ? V<R>{R(1), R(1), R(1)} : texture_value<R>(sc, texture, pt);
     thr = {thr.x * att.x, thr.y * att.y, thr.z * att.z};
     o = pt;
     d = nd;
@@ -678,8 +728,8 @@ __device__ __forceinline__ bool shade(const DevScene<R>& sc, Pcg32& g, V<R>& o, 
 }
 
 // ---- camera ray of path (px, py, s): src/camera.zig:59-90 ---------------------------------------
-template <class R>
-__device__ __forceinline__ void camera_ray(const DevCamera<R>& cam, Pcg32& g, uint32_t px, uint32_t py, V<R>& o, V<R>& d,
+template <class R, class G>
+__device__ __forceinline__ void camera_ray(const DevCamera<R>& cam, G& g, uint32_t px, uint32_t py, V<R>& o, V<R>& d,
                                            R& time) {
     const R x = (R)px + (uniform<R>(g) - R(0.5));
     const R y = (R)py + (uniform<R>(g) - R(0.5));
@@ -968,7 +1018,7 @@ __device__ __forceinline__ uint32_t bvh_leaf_entry(const DevScene<R>& sc, BvhQue
     const RayBasis<R> b = make_basis<R>(ud, o); // same filter as the flat list (hipcc shares it between both entries)
     const R p1 = fm(v.z, time * b.e1z, fm(v.x, time * b.e1x, basis_p1<R>(b, c.x, c.z)));
     const R p2 = fm(v.z, time * b.e2z, fm(v.y, time * b.e2y, fm(v.x, time * b.e2x, basis_p2<R>(b, c.x, c.y, c.z))));
-    return basis_disc<R>(p1, p2, c.w) >= R(0) ? slot + 1u : 0u;
+    return sphere_candidate<R>(p1, p2, c.w) ? slot + 1u : 0u;
 }
 
 // Phase C — the f64 quadratic of a parked sphere candidate (same arithmetic as narrow_phase()).
@@ -1208,6 +1258,123 @@ __global__ __launch_bounds__(256) void tonemap_kernel(const float* __restrict__ 
     s = s > 0.0 ? s : 0.0; // utils.max(x, low)
     s = s < 1.0 ? s : 1.0; // utils.min(.., high)
     out[i] = (uint8_t)(s * 255.0);
+}
+
+// ---- known-answer entry (rayz_hip_kat): the kernel's own device functions on caller-supplied inputs -----------------
+// One thread per record; records are RAYZ_KAT_IN_STRIDE doubles in, RAYZ_KAT_OUT_STRIDE doubles out (layouts in
+// include/rayz_hip.h).  Inputs are narrowed to R exactly as the scene and camera are when they cross the ABI.
+constexpr int kKatIn = 48, kKatOut = 12;
+template <class R> __global__ __launch_bounds__(64) void kat_kernel(uint32_t op, const double* in, uint32_t n, double* out) {
+    typedef typename VecOf<R>::type r4;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double* a = in + (size_t)i * kKatIn;
+    double* r = out + (size_t)i * kKatOut;
+    for (int k = 0; k < kKatOut; ++k) r[k] = 0.0;
+    auto v3 = [&](int k) { return V<R>{(R)a[k], (R)a[k + 1], (R)a[k + 2]}; };
+    auto put3 = [&](int k, V<R> v) { r[k] = (double)v.x, r[k + 1] = (double)v.y, r[k + 2] = (double)v.z; };
+    switch (op) {
+    case 0: { // REFRACT: ud(3) n(3) eta -> dir(3)
+        const V<R> ud = v3(0), nrm = v3(3);
+        put3(0, refract<R>(ud, nrm, -dot3(ud, nrm), (R)a[6]));
+        break;
+    }
+    case 1: // REFLECTANCE: cos, eta -> r
+        r[0] = (double)reflectance<R>((R)a[0], (R)a[1]);
+        break;
+    case 2: { // GET_RAY: from du dv pxo defu defv (18) defocus px py n_u u[..] -> origin(3) dir(3) time draws
+        DevCamera<R> cam;
+        for (int k = 0; k < 3; ++k) {
+            cam.from[k] = (R)a[k], cam.du[k] = (R)a[3 + k], cam.dv[k] = (R)a[6 + k], cam.pxo[k] = (R)a[9 + k];
+            cam.defu[k] = (R)a[12 + k], cam.defv[k] = (R)a[15 + k];
+        }
+        cam.defocus = a[18] != 0.0 ? 1u : 0u;
+        cam._pad = 0;
+        ListRng g{a + 22, (uint32_t)a[21], 0u};
+        V<R> o, d;
+        R time;
+        camera_ray<R>(cam, g, (uint32_t)a[19], (uint32_t)a[20], o, d, time);
+        put3(0, o);
+        put3(3, d);
+        r[6] = (double)time;
+        r[7] = (double)g.i;
+        break;
+    }
+    case 3: { // BOX_HIT: lo(3) hi(3) o(3) d(3) tmin tmax -> hit, t_entry
+        const V<R> d = v3(9);
+        BvhQuery<R> q;
+        bvh_begin<R>(q, d, 1u);
+        q.tbest = (R)a[13];
+        R t0;
+        const r4 lo = {(R)a[0], (R)a[1], (R)a[2], R(0)}, hi = {(R)a[3], (R)a[4], (R)a[5], R(0)};
+        r[0] = bvh_box_hit<R>(lo, hi, q, v3(6), (R)a[12], t0) ? 1.0 : 0.0;
+        r[1] = (double)t0;
+        break;
+    }
+    case 4: { // SPHERE_HIT: c(3) v(3) radius o(3) d(3) time tmin tmax -> hit t point(3) normal(3) front filter
+        const V<R> o = v3(7), d = v3(10);
+        const R time = (R)a[13], tmin = (R)a[14];
+        const r4 c = {(R)a[0], (R)a[1], (R)a[2], (R)a[16]}, v = {(R)a[3], (R)a[4], (R)a[5], R(0)}; // a[16]: padded r², from the host
+        const V<R> ud = unit(d);
+        const RayBasis<R> b = make_basis<R>(ud, o);
+        const R p1 = fm(v.z, time * b.e1z, fm(v.x, time * b.e1x, basis_p1<R>(b, c.x, c.z)));
+        const R p2 = fm(v.z, time * b.e2z, fm(v.y, time * b.e2y, fm(v.x, time * b.e2x, basis_p2<R>(b, c.x, c.y, c.z))));
+        const bool cand = sphere_candidate<R>(p1, p2, c.w);
+        r[9] = cand ? 1.0 : 0.0;
+        R tbest = (R)a[15];
+        int ibest = -1;
+        if (cand) {
+            const double ddx = d.x, ddy = d.y, ddz = d.z;
+            const double inv_a2 = 1.0 / fm(ddz, ddz, fm(ddy, ddy, ddx * ddx));
+            const d4 c64 = {a[0], a[1], a[2], a[6] * a[6]}, v64 = {a[3], a[4], a[5], 0.0};
+            // the reference accepts t <= tmax (src/geom.zig:56-58); the kernel's running best is exclusive with a tie
+            // rule on the pool index: index 1 > the initial -1 makes a tie with tmax an accept here too
+            narrow_eval<R>(c64, v64, 1, o, d, time, inv_a2, tmin, tbest, ibest);
+        }
+        if (ibest >= 0) {
+            V<R> pt, nrm;
+            sphere_hit_record<R>(c, v, o, d, time, tbest, pt, nrm);
+            const bool front = face_forward<R>(d, nrm);
+            r[0] = 1.0, r[1] = (double)tbest;
+            put3(2, pt);
+            put3(5, nrm);
+            r[8] = front ? 1.0 : 0.0;
+        }
+        break;
+    }
+    case 5: { // SCATTER: kind method param o(3) d(3) point(3) normal(3) front n_u u[..] -> ok dir(3) draws
+        const uint32_t kind = (uint32_t)a[0], method = (uint32_t)a[1];
+        const R param = (R)a[2];
+        const V<R> d = v3(6);
+        ListRng g{a + 17, (uint32_t)a[16], 0u};
+        V<R> nd{R(0), R(0), R(0)};
+        const bool ok = scatter_dir<R>(kind, method, param, R(1) / param, g, d, unit(d), v3(9), v3(12), a[15] != 0.0, nd);
+        r[0] = ok ? 1.0 : 0.0;
+        put3(1, nd);
+        r[4] = (double)g.i;
+        break;
+    }
+    case 6: // CHECKER: p(3) scale -> parity
+        r[0] = (double)checker_parity<R>(v3(0), (R)a[3]);
+        break;
+    case 7: { // BACKGROUND: d(3) -> colour(3)
+        put3(0, background<R>(unit(v3(0))));
+        break;
+    }
+    case 8: { // TRIANGLE_HIT (build-defined): v0(3) v1(3) v2(3) o(3) d(3) tmin tmax -> hit t filter>=0
+        const V<R> v0 = v3(0), o = v3(9), d = v3(12);
+        const V<R> e1{(R)(a[3] - a[0]), (R)(a[4] - a[1]), (R)(a[5] - a[2])}, e2{(R)(a[6] - a[0]), (R)(a[7] - a[1]), (R)(a[8] - a[2])};
+        const R f = tri_filter<R>(v0, e1, e2, o, d);
+        R tbest = (R)a[16];
+        int ibest = -1;
+        tri_accept<R>(f, v0, e1, e2, o, d, (R)a[15], 1, tbest, ibest);
+        r[0] = ibest >= 0 ? 1.0 : 0.0;
+        r[1] = ibest >= 0 ? (double)tbest : 0.0;
+        r[2] = f >= R(0) ? 1.0 : 0.0;
+        break;
+    }
+    default: break;
+    }
 }
 
 } // namespace rayz_dev

@@ -116,6 +116,7 @@ template <class R> struct SceneBuffers {
     r4* bvh_nodes = nullptr; // BVH traversal only
     r4* bvh_leaf = nullptr;
     uint32_t nt_pad = 0, bvh_leaf_stride = 2, bvh_n_inner = 0;
+    double pad_S = 0; // the origin bound S the filter radii of these buffers were padded for
     bool ready = false, bvh_ready = false;
     void release() {
         (void)hipFree(tri);
@@ -156,10 +157,27 @@ struct NarrowBuffers {
 
 uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
 
+double norm3(const double* v) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
+
+// ---- conservative reject filter ---------------------------------------------------------------
+// The scan and the BVH leaves test r_pad² − p1² − p2² ≥ 0 in R with r_pad = r + E, E = 32·u·(|c| + |v| + r + S):
+// u = unit roundoff of R, S = a bound on |o| of every ray the render can produce (camera lens, hit points on any
+// hittable).  The padded square is rounded UP to R.  Candidates are decided by the f64 narrow phase, so the padding
+// changes no image — it only guarantees that no sphere with an f64 discriminant ≥ 0 is filtered out.
+template <class R> constexpr double unit_roundoff() { return sizeof(R) == 4 ? 5.9604644775390625e-08 : 1.1102230246251565e-16; }
+template <class R> R pad_radius2(const RayzSphere& q, double S) {
+    const double E = 32.0 * unit_roundoff<R>() * (norm3(q.center) + norm3(q.velocity) + std::fabs(q.radius) + S);
+    const double rp = std::fabs(q.radius) + E;
+    return rayz_bvh::roundUp<R>(rp * rp);
+}
+double scene_origin_bound(const RayzScene* s);
+double camera_origin_bound(const RayzCameraDesc* c) { return norm3(c->look_from) + norm3(c->defocus_u) + norm3(c->defocus_v); }
+
 } // namespace
 
 struct RayzScene {
     int device = -1; // HIP ordinal this scene's buffers live on; bound at creation (_on) or at the first render
+    double origin_bound = -1; // max |hit point| over the pool (lazily)
     std::vector<RayzSphere> spheres;
     std::vector<RayzMaterial> materials;
     std::vector<RayzTexture> textures;
@@ -180,6 +198,14 @@ struct RayzScene {
 };
 
 namespace {
+
+// Every scattered ray starts at a hit point: on a sphere (|p| ≤ |c| + |v| + r, t ∈ [0,1)) or on a triangle.
+double scene_origin_bound(const RayzScene* s) {
+    double S = 0;
+    for (const RayzSphere& q : s->spheres) S = std::max(S, norm3(q.center) + norm3(q.velocity) + std::fabs(q.radius));
+    for (const RayzTriangle& q : s->triangles) S = std::max({S, norm3(q.v0), norm3(q.v1), norm3(q.v2)});
+    return S * (1.0 + 1e-3);
+}
 
 template <class T> hipError_t put(T** dst, const std::vector<T>& v) {
     const size_t bytes = v.size() * sizeof(T);
@@ -243,10 +269,9 @@ template <class R> int upload_body(RayzScene* s, SceneBuffers<R>& b) {
     if (rc != RAYZ_OK) return rc;
     const R ninf = -std::numeric_limits<R>::infinity();
     const r4 pad = {R(0), R(0), R(0), ninf}; // r² = -inf: the discriminant is -inf (or NaN), never ≥ 0
-    auto rec = [&](uint32_t pool) {
+    auto rec = [&](uint32_t pool) { // w = the PADDED r² of the conservative filter
         const RayzSphere& q = s->spheres[pool];
-        const R r = (R)q.radius;
-        return r4{(R)q.center[0], (R)q.center[1], (R)q.center[2], r * r};
+        return r4{(R)q.center[0], (R)q.center[1], (R)q.center[2], pad_radius2<R>(q, b.pad_S)};
     };
     // static / mov-Y streams: blocks of G spheres, SoA inside a block (field f of sphere k of block g at
     // g·F·G + f·G + k), pad spheres {0, 0, 0, r² = -inf, vy = 0}
@@ -306,8 +331,14 @@ template <class R> int upload_body(RayzScene* s, SceneBuffers<R>& b) {
     return RAYZ_OK;
 }
 
-template <class R> int upload(RayzScene* s, SceneBuffers<R>& b) {
-    if (b.ready) return RAYZ_OK;
+// `S` = the origin bound this render needs.  Buffers padded for a smaller bound are rebuilt (for twice the bound, so
+// that a moving camera does not rebuild every frame); the padding changes no image.
+template <class R> int upload(RayzScene* s, SceneBuffers<R>& b, double S) {
+    if (b.ready && b.pad_S >= S) return RAYZ_OK;
+    const bool again = b.ready;
+    if (again) HIP_TRY(hipDeviceSynchronize());
+    b.release();
+    b.pad_S = again ? 2.0 * S : S;
     const int rc = upload_body<R>(s, b);
     if (rc != RAYZ_OK) b.release();
     return rc;
@@ -378,8 +409,7 @@ template <class R> int upload_bvh_body(RayzScene* s, SceneBuffers<R>& b) {
     for (uint32_t prim : t.order) {
         if (prim < ns) {
             const RayzSphere& q = s->spheres[prim];
-            const R r = (R)q.radius;
-            leaf.push_back(r4{(R)q.center[0], (R)q.center[1], (R)q.center[2], r * r});
+            leaf.push_back(r4{(R)q.center[0], (R)q.center[1], (R)q.center[2], pad_radius2<R>(q, b.pad_S)});
             leaf.push_back(r4{(R)q.velocity[0], (R)q.velocity[1], (R)q.velocity[2], Bits<R>::from(prim)});
             if (b.bvh_leaf_stride == 3) leaf.push_back(r4{R(0), R(0), R(0), R(0)});
         } else {
@@ -556,7 +586,8 @@ int render_impl(RayzScene* s, const DeviceCtx& ctx, SceneBuffers<R>& b, const Ra
     if (s->spheres.size() + s->triangles.size() >= (1u << 27))
         return fail(RAYZ_ERR_BAD_ARG, "too many hittables for the device layout");
     if (s->last_stream && s->last_stream != stream) HIP_TRY(hipStreamSynchronize(s->last_stream)); // previous render done
-    int rc = upload<R>(s, b);
+    if (s->origin_bound < 0) s->origin_bound = scene_origin_bound(s);
+    int rc = upload<R>(s, b, std::max(s->origin_bound, camera_origin_bound(cam)));
     if (rc != RAYZ_OK) return rc;
     if (use_bvh) {
         rc = upload_bvh<R>(s, b);
@@ -1185,6 +1216,52 @@ int rayz_hip_tonemap_u8(const float* d_rgb, uint8_t* d_rgb8, size_t n_pixels, vo
         hipLaunchKernelGGL(tonemap_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream ? (hipStream_t)stream : own,
                            d_rgb, d_rgb8, n);
         HIP_TRY(hipGetLastError());
+        return (int)RAYZ_OK;
+    });
+}
+
+// ---- known answers: the kernel's device functions on caller inputs ---------------------------------------------
+int rayz_hip_kat(uint32_t op, uint32_t precision, const double* in, uint32_t n, double* out) {
+    return guarded([&] {
+        if (op > RAYZ_KAT_TRIANGLE_HIT) return fail(RAYZ_ERR_BAD_ARG, "bad known-answer op %u", op);
+        if (precision > RAYZ_PRECISION_F64) return fail(RAYZ_ERR_BAD_ARG, "bad precision %u", precision);
+        if (!n) return (int)RAYZ_OK;
+        if (!in || !out) return fail(RAYZ_ERR_BAD_ARG, "null buffer");
+        int device;
+        hipStream_t stream;
+        {
+            std::lock_guard<std::mutex> lock(g_mu);
+            device = g_default;
+            if (device < 0) return fail(RAYZ_ERR_NO_DEVICE, "rayz_hip_init has not succeeded");
+            stream = g_ctx[device].stream;
+        }
+        std::vector<double> host(in, in + (size_t)n * RAYZ_KAT_IN_STRIDE);
+        for (uint32_t i = 0; i < n; ++i) { // what the scene upload would have prepared for these hittables
+            double* a = host.data() + (size_t)i * RAYZ_KAT_IN_STRIDE;
+            if (op == RAYZ_KAT_SPHERE_HIT) {
+                RayzSphere q{};
+                for (int k = 0; k < 3; ++k) q.center[k] = a[k], q.velocity[k] = a[3 + k];
+                q.radius = a[6];
+                const double S = std::max(norm3(a + 7), norm3(q.center) + norm3(q.velocity) + std::fabs(q.radius));
+                a[16] = precision == RAYZ_PRECISION_F32 ? (double)pad_radius2<float>(q, S) : pad_radius2<double>(q, S);
+            }
+        }
+        DeviceScope scope(device);
+        double *d_in = nullptr, *d_out = nullptr;
+        const size_t in_bytes = host.size() * sizeof(double), out_bytes = (size_t)n * RAYZ_KAT_OUT_STRIDE * sizeof(double);
+        hipError_t e = hipMalloc((void**)&d_in, in_bytes);
+        if (e == hipSuccess) e = hipMalloc((void**)&d_out, out_bytes);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_in, host.data(), in_bytes, hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess) {
+            if (precision == RAYZ_PRECISION_F32) hipLaunchKernelGGL(kat_kernel<float>, dim3((n + 63) / 64), dim3(64), 0, stream, op, d_in, n, d_out);
+            else hipLaunchKernelGGL(kat_kernel<double>, dim3((n + 63) / 64), dim3(64), 0, stream, op, d_in, n, d_out);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        (void)hipFree(d_in);
+        (void)hipFree(d_out);
+        if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? RAYZ_ERR_OOM : RAYZ_ERR_HIP, "rayz_hip_kat: %s", hipGetErrorString(e));
         return (int)RAYZ_OK;
     });
 }

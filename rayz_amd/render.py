@@ -120,6 +120,16 @@ class MultiScene:
             pass
 
 
+def kat(op: int, records, precision: int = capi.PRECISION_F32) -> np.ndarray:
+    """`rayz_hip_kat`: the trace kernels' own device functions on (n, KAT_IN_STRIDE) float64 records."""
+    lib = capi.load()
+    rec = np.ascontiguousarray(records, dtype=np.float64).reshape(-1, capi.KAT_IN_STRIDE)
+    out = np.zeros((len(rec), capi.KAT_OUT_STRIDE))
+    D = C.POINTER(C.c_double)
+    capi.check(lib, lib.rayz_hip_kat(op, precision, rec.ctypes.data_as(D), len(rec), out.ctypes.data_as(D)), "rayz_hip_kat")
+    return out
+
+
 def tonemap_u8(rgb_ptr: int, out_ptr: int, n_pixels: int, stream: int = 0) -> None:
     lib = capi.load()
     capi.check(lib, lib.rayz_hip_tonemap_u8(C.c_void_p(rgb_ptr), C.c_void_p(out_ptr), n_pixels, C.c_void_p(stream)),

@@ -95,6 +95,18 @@ extern "c" fn rayz_hip_render(
     stats: ?*RayzRenderStats,
 ) c_int;
 
+/// All GPUs of the node behind the same single call: rows are dealt to `devices` in interleaved tiles, each device
+/// traces its rows, one RCCL gather over xGMI reassembles the frame into `rgb_out` (host, h*w*3).
+extern "c" fn rayz_hip_render_multi(
+    devices: [*]const c_int,
+    n_devices: c_int,
+    scene: *const RayzSceneDesc,
+    camera: *const RayzCameraDesc,
+    params: *const RayzRenderParams,
+    rgb_out: [*]f32,
+    stats: ?*RayzRenderStats,
+) c_int;
+
 fn v3(v: vec.V3) [3]f64 {
     return .{ v.x, v.y, v.z };
 }
@@ -102,6 +114,7 @@ fn v3(v: vec.V3) [3]f64 {
 pub const HipOptions = struct {
     seed: ?u64 = null, // null: next u64 of the Tracer's own DefaultPrng
     tmin: f64 = 1e-3,
+    devices: []const c_int = &.{}, // empty: device 0; e.g. &.{ 0, 1, 2, 3, 4, 5, 6, 7 } for a whole MI355X node
 };
 
 /// The body of `Tracer.render()`: flatten → one extern call → widen f32 → f64 into img.pixels.
@@ -157,7 +170,11 @@ pub fn renderHip(self: *renderer.Tracer, opt: HipOptions) !usize {
     const rgb = try a.alloc(f32, self.img.w * self.img.h * 3);
     defer a.free(rgb);
     var stats: RayzRenderStats = undefined;
-    if (rayz_hip_init(0) != 0 or rayz_hip_render(&scene, &cam, &params, rgb.ptr, &stats) != 0) {
+    const rc = if (opt.devices.len == 0)
+        (if (rayz_hip_init(0) != 0) @as(c_int, -4) else rayz_hip_render(&scene, &cam, &params, rgb.ptr, &stats))
+    else
+        rayz_hip_render_multi(opt.devices.ptr, @intCast(opt.devices.len), &scene, &cam, &params, rgb.ptr, &stats);
+    if (rc != 0) {
         std.debug.print("rayz_hip: {s}\n", .{rayz_hip_last_error()});
         return error.GpuRenderFailed;
     }

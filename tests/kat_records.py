@@ -1,0 +1,162 @@
+"""Builders of rayz_hip_kat records (include/rayz_hip.h: RayzKatOp) shared by the CPU and GPU known-answer tests."""
+import numpy as np
+
+from rayz_amd import capi
+
+S_IN, S_OUT = capi.KAT_IN_STRIDE, capi.KAT_OUT_STRIDE
+
+
+def f32r(x):
+    """Round to f32-representable values, so that an f32 and an f64 evaluation start from the same numbers."""
+    return np.asarray(x, dtype=np.float64).astype(np.float32).astype(np.float64)
+
+
+def blank(n):
+    return np.zeros((n, S_IN))
+
+
+def unit(v):
+    v = np.asarray(v, dtype=np.float64)
+    return v / np.linalg.norm(v, axis=-1, keepdims=True)
+
+
+def uniforms(rng, shape):
+    """Uniforms of the form k / 2^24: exactly what the kernel's f32 stream can produce, exact in f64 too."""
+    return rng.integers(0, 1 << 24, size=shape).astype(np.float64) / float(1 << 24)
+
+
+# ---- the reference's own vectors ----------------------------------------------------------------------------
+def refract_reference():  # src/material.zig:213-223
+    rec = blank(1)
+    rec[0, 0:3] = unit([-0.3125, -0.3125, -1.0])
+    rec[0, 3:6] = [-0.558127, -0.558127, 0.613994]
+    rec[0, 6] = 1.0 / 1.5
+    return rec, np.array([0.144881, 0.144881, -0.978784])
+
+
+def get_ray_reference(camera_desc):  # src/renderer.zig:129-149 (focus sqrt(12), defocus 0: SURVEY.md §4)
+    rec = blank(2)
+    c = camera_desc
+    for i, (px, py) in enumerate([(0, 0), (112, 199)]):
+        rec[i, 0:18] = np.concatenate([np.array(x) for x in (c.look_from, c.px_du, c.px_dv, c.px_origin, c.defocus_u,
+                                                               c.defocus_v)])
+        rec[i, 18], rec[i, 19], rec[i, 20], rec[i, 21] = c.defocus, px, py, 0  # no list: every draw is 0.5 = no jitter
+    want = np.array([[-0.935834, 0.815856, -7.75169], [-0.998817, -4.18732, -2.8115]])
+    return rec, want
+
+
+def box_hit_reference():  # src/hit.zig:247-279 ("bbox hit", "bbox hit 2")
+    rows = [
+        ([0] * 3, [1] * 3, [-1] * 3, [1] * 3, 0, 10, 1),
+        ([0] * 3, [1] * 3, [-1] * 3, [-1] * 3, 0, 10, 0),
+        ([0] * 3, [1] * 3, [-1] * 3, [0.5] * 3, 0, 10, 1),
+        ([-1000, -2000, -1000], [1000, 2, 1000], [13, 2, 3], [-9.6, -1.5, -2.3], 0, 10, 1),
+    ]
+    rec = blank(len(rows))
+    for i, (lo, hi, o, d, tmin, tmax, _) in enumerate(rows):
+        rec[i, 0:3], rec[i, 3:6], rec[i, 6:9], rec[i, 9:12], rec[i, 12], rec[i, 13] = lo, hi, o, d, tmin, tmax
+    return rec, np.array([r[-1] for r in rows], dtype=np.float64)
+
+
+# ---- random records ---------------------------------------------------------------------------------------------
+def random_sphere_hits(rng, n, big=False):
+    """(ray, sphere) pairs: rays aimed near the sphere so that about half hit; some spheres move; some rays start
+    inside.  `big` adds the r = 1000 ground-sphere regime (grazing rays from points on its surface)."""
+    rec = blank(n)
+    c = rng.uniform(-10, 10, (n, 3))
+    r = rng.uniform(0.05, 2.0, n)
+    v = np.where(rng.random((n, 1)) < 0.4, rng.uniform(-0.5, 0.5, (n, 3)) * [[0, 1, 0]], 0.0)
+    gen = rng.random(n) < 0.1
+    v = np.where(gen[:, None], rng.uniform(-0.5, 0.5, (n, 3)), v)
+    if big:
+        c[: n // 4] = [0, -1000, 0]
+        r[: n // 4] = 1000.0
+        v[: n // 4] = 0
+    o = c + unit(rng.normal(size=(n, 3))) * (r * rng.uniform(0.3, 8.0, n))[:, None]
+    if big:
+        k = n // 4
+        o[:k] = c[:k] + unit(rng.normal(size=(k, 3)) + [0, 3, 0]) * (r[:k] * (1 + rng.uniform(0, 1e-3, k)))[:, None]
+    time = uniforms(rng, n)
+    aim = c + v * time[:, None] + unit(rng.normal(size=(n, 3))) * (r * rng.uniform(0, 2.0, n))[:, None]
+    d = (aim - o) * rng.uniform(0.2, 5.0, (n, 1))
+    rec[:, 0:3], rec[:, 3:6], rec[:, 6] = f32r(c), f32r(v), f32r(r)
+    rec[:, 7:10], rec[:, 10:13], rec[:, 13] = f32r(o), f32r(d), time
+    rec[:, 14], rec[:, 15] = 1e-3, np.inf
+    return rec
+
+
+def random_scatters(rng, n, n_u=30):
+    rec = blank(n)
+    kind = rng.integers(0, 3, n)
+    method = np.where(kind == 0, rng.integers(0, 3, n), 2)
+    param = np.where(kind == 1, np.where(rng.random(n) < 0.3, 0.0, rng.uniform(0, 1.5, n)), rng.uniform(1.1, 2.4, n))
+    nrm = unit(rng.normal(size=(n, 3)))
+    front = rng.random(n) < 0.7
+    d = unit(rng.normal(size=(n, 3)))
+    dn = (d * nrm).sum(1, keepdims=True)
+    d = np.where(dn > 0, d - 2 * dn * nrm, d)  # Hit.init: the stored normal always opposes the ray
+    d = d * rng.uniform(0.3, 4.0, (n, 1))
+    pt = rng.uniform(-20, 20, (n, 3))
+    rec[:, 0], rec[:, 1], rec[:, 2] = kind, method, f32r(param)
+    rec[:, 3:6] = f32r(pt - d)
+    rec[:, 6:9], rec[:, 9:12], rec[:, 12:15] = f32r(d), f32r(pt), f32r(nrm)
+    rec[:, 15], rec[:, 16] = front, n_u
+    rec[:, 17:17 + n_u] = uniforms(rng, (n, n_u))
+    return rec
+
+
+def random_get_rays(rng, n, camera_desc, n_u=12):
+    rec = blank(n)
+    c = camera_desc
+    rec[:, 0:18] = f32r(np.concatenate([np.array(x) for x in (c.look_from, c.px_du, c.px_dv, c.px_origin, c.defocus_u,
+                                                               c.defocus_v)]))[None, :]
+    rec[:, 18] = c.defocus
+    rec[:, 19], rec[:, 20], rec[:, 21] = rng.integers(0, 1920, n), rng.integers(0, 1080, n), n_u
+    rec[:, 22:22 + n_u] = uniforms(rng, (n, n_u))
+    return rec
+
+
+def random_refracts(rng, n):
+    """Non-TIR only (eta * sin <= 0.98): the reference's bare sqrt is NaN beyond, the kernel clamps."""
+    rec = blank(n)
+    nrm = unit(rng.normal(size=(n, 3)))
+    t = unit(np.cross(nrm, rng.normal(size=(n, 3))))
+    eta = np.where(rng.random(n) < 0.5, 1 / 1.5, 1.5) * rng.uniform(0.8, 1.2, n)
+    smax = np.minimum(0.98 / eta, 0.999)
+    sin = rng.uniform(0, 1, n) * smax
+    ud = -np.sqrt(1 - sin ** 2)[:, None] * nrm + sin[:, None] * t
+    rec[:, 0:3], rec[:, 3:6], rec[:, 6] = unit(f32r(ud)), unit(f32r(nrm)), f32r(eta)
+    return rec
+
+
+def random_boxes(rng, n):
+    rec = blank(n)
+    lo = rng.uniform(-10, 10, (n, 3))
+    hi = lo + rng.uniform(0.01, 6, (n, 3))
+    o = rng.uniform(-15, 15, (n, 3))
+    aim = lo + (hi - lo) * rng.uniform(-0.5, 1.5, (n, 3))
+    d = (aim - o) * rng.uniform(0.1, 3, (n, 1))
+    rec[:, 0:3], rec[:, 3:6], rec[:, 6:9], rec[:, 9:12] = f32r(lo), f32r(hi), f32r(o), f32r(d)
+    rec[:, 12], rec[:, 13] = 1e-3, np.where(rng.random(n) < 0.5, np.inf, rng.uniform(0.1, 3, n))
+    return rec
+
+
+def random_checkers(rng, n):
+    rec = blank(n)
+    rec[:, 0:3] = f32r(rng.uniform(-50, 50, (n, 3)))
+    rec[:, 3] = f32r(rng.choice([0.32, 0.5, 0.11, 2.0, 0.7], n))
+    return rec
+
+
+def random_triangles(rng, n):
+    rec = blank(n)
+    v0 = rng.uniform(-5, 5, (n, 3))
+    v1 = v0 + rng.uniform(-2, 2, (n, 3))
+    v2 = v0 + rng.uniform(-2, 2, (n, 3))
+    w = rng.dirichlet([1, 1, 1], n) * rng.uniform(0.2, 1.8, (n, 1))
+    aim = v0 * w[:, :1] + v1 * w[:, 1:2] + v2 * w[:, 2:3] + (1 - w.sum(1, keepdims=True)) * v0
+    o = rng.uniform(-10, 10, (n, 3))
+    d = (aim - o) * rng.uniform(0.2, 3, (n, 1))
+    rec[:, 0:3], rec[:, 3:6], rec[:, 6:9], rec[:, 9:12], rec[:, 12:15] = f32r(v0), f32r(v1), f32r(v2), f32r(o), f32r(d)
+    rec[:, 15], rec[:, 16] = 1e-3, np.inf
+    return rec

@@ -10,6 +10,8 @@
 // The host mirror's render() calls the HIP library; this CPU build has none.
 extern "C" int rayz_hip_render(const RayzSceneDesc*, const RayzCameraDesc*, const RayzRenderParams*, float*, RayzRenderStats*) { return RAYZ_ERR_NO_DEVICE; }
 extern "C" int rayz_hip_render_f64(const RayzSceneDesc*, const RayzCameraDesc*, const RayzRenderParams*, double*, RayzRenderStats*) { return RAYZ_ERR_NO_DEVICE; }
+extern "C" int rayz_hip_render_multi(const int*, int, const RayzSceneDesc*, const RayzCameraDesc*, const RayzRenderParams*, float*, RayzRenderStats*) { return RAYZ_ERR_NO_DEVICE; }
+extern "C" int rayz_hip_render_multi_f64(const int*, int, const RayzSceneDesc*, const RayzCameraDesc*, const RayzRenderParams*, double*, RayzRenderStats*) { return RAYZ_ERR_NO_DEVICE; }
 extern "C" const char* rayz_hip_last_error(void) { return "no device in the sanitizer build"; }
 
 static int run(rayz::Tracer& t, const char* name) {

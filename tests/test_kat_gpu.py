@@ -1,0 +1,81 @@
+"""The HIP device functions themselves — `rayz_hip_kat` runs the trace kernels' own inlined functions, one GPU thread
+per record — held (1) to the reference's test vectors directly and (2) to the oracle's mode B bit for bit on random
+records of every op, f32 and f64.  Together with tests/test_kat_cpu.py (mode B == mode A deterministically) this
+closes the chain device code -> mode B -> the reference's functions without a statistical link."""
+import numpy as np
+import pytest
+
+import kat_records as K
+from rayz_amd import capi
+
+pytestmark = pytest.mark.gpu
+F32, F64 = capi.PRECISION_F32, capi.PRECISION_F64
+
+
+@pytest.mark.parametrize("prec", [F32, F64])
+def test_device_functions_on_the_reference_vectors(gpu, oracle, prec):
+    rec, want = K.refract_reference()  # src/material.zig:213-223
+    assert gpu.kat(capi.KAT_REFRACT, rec, prec)[0, :3] == pytest.approx(want, rel=1e-4)
+    cam = capi.CameraDesc()
+    oracle.load().rayz_oracle_camera_init(90, 12 ** 0.5, 0, oracle.d3([-2, 2, 1]), oracle.d3([0, 0, -1]),
+                                          oracle.d3([0, 1, 0]), 225, 400, cam)
+    rec, want = K.get_ray_reference(cam)  # src/renderer.zig:129-149
+    got = gpu.kat(capi.KAT_GET_RAY, rec, prec)
+    assert got[:, 0:3].tolist() == [[-2, 2, 1]] * 2 and got[:, 3:6] == pytest.approx(want, rel=1e-5)
+    rec, want = K.box_hit_reference()  # src/hit.zig:247-279
+    assert gpu.kat(capi.KAT_BOX_HIT, rec, prec)[:, 0].tolist() == want.tolist()
+
+
+@pytest.mark.parametrize("prec", [F32, F64])
+def test_device_functions_equal_mode_b_bit_for_bit(gpu, oracle, prec):
+    rng = np.random.default_rng(77)
+    cam = capi.CameraDesc()
+    oracle.load().rayz_oracle_camera_init(20, 10.0, 0.6, oracle.d3([13, 2, 3]), oracle.d3([0, 0, 0]),
+                                          oracle.d3([0, 1, 0]), 1080, 1920, cam)
+    refl = K.blank(20_000)
+    refl[:, 0], refl[:, 1] = rng.uniform(0, 1, 20_000), rng.uniform(0.4, 2.5, 20_000)
+    bg = K.blank(20_000)
+    bg[:, 0:3] = rng.normal(size=(20_000, 3))
+    cases = [
+        (capi.KAT_REFRACT, K.random_refracts(rng, 50_000)),
+        (capi.KAT_REFLECTANCE, refl),
+        (capi.KAT_GET_RAY, K.random_get_rays(rng, 50_000, cam)),
+        (capi.KAT_BOX_HIT, K.random_boxes(rng, 100_000)),
+        (capi.KAT_SPHERE_HIT, K.random_sphere_hits(rng, 100_000)),
+        (capi.KAT_SPHERE_HIT, K.random_sphere_hits(rng, 100_000, big=True)),
+        (capi.KAT_SCATTER, K.random_scatters(rng, 100_000)),
+        (capi.KAT_CHECKER, K.random_checkers(rng, 50_000)),
+        (capi.KAT_BACKGROUND, bg),
+        (capi.KAT_TRIANGLE_HIT, K.random_triangles(rng, 100_000)),
+    ]
+    for op, rec in cases:
+        got, want = gpu.kat(op, rec, prec), oracle.kat_b(op, rec, prec)
+        same = (got == want) | (np.isnan(got) & np.isnan(want))
+        assert same.all(), (op, prec, int((~same).any(1).sum()), np.flatnonzero((~same).any(1))[:5].tolist())
+
+
+def test_conservative_filter_on_the_device(gpu, oracle):
+    """Grazing rays on the r = 1000 ground sphere, the regime where the f32 filter used to be able to drop a sphere
+    the f64 quadratic hits: whenever the reference's hitInner (mode A) hits, the device filter
+    must have passed the pair on."""
+    rng = np.random.default_rng(4)
+    n = 200_000
+    rec = K.blank(n)
+    c, r = np.array([0.0, -1000.0, 0.0]), 1000.0
+    o = c + K.unit(rng.normal(size=(n, 3)) + [0, 2, 0]) * (r * (1 + 10.0 ** rng.uniform(-7, -2, n)))[:, None]
+    # aim at a point on the horizon circle seen from o, moved in or out by up to ~1e-5 of the radius
+    up = K.unit(o - c)
+    tang = K.unit(np.cross(up, rng.normal(size=(n, 3))))
+    h = np.linalg.norm(o - c, axis=1) - r
+    reach = np.sqrt(2 * r * h + h * h)
+    dip = (h / reach + rng.normal(size=n) * 1e-5)[:, None]  # tangent slope +- a hair
+    d = (tang - up * dip) * rng.uniform(0.5, 2.0, (n, 1))
+    rec[:, 0:3], rec[:, 6] = c, r
+    rec[:, 7:10], rec[:, 10:13] = K.f32r(o), K.f32r(d)
+    rec[:, 13], rec[:, 14], rec[:, 15] = 0.5, 1e-3, np.inf
+    a = oracle.kat_a(capi.KAT_SPHERE_HIT, rec)
+    g = gpu.kat(capi.KAT_SPHERE_HIT, rec, F32)
+    hit = a[:, 0] == 1
+    assert 0.2 < hit.mean() < 0.8  # the set straddles the tangent
+    assert (g[hit, 9] == 1).all(), int((g[hit, 9] == 0).sum())
+    assert ((g[:, 9] == 1) & ~hit).mean() < 0.5  # and the padding is thin: it does not just pass everything
