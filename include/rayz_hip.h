@@ -146,8 +146,8 @@ typedef struct RayzRenderParams {
     double tmin;             /* src/renderer.zig:107 passes 1e-10 */
     uint32_t precision;      /* RayzPrecision */
     uint32_t traversal;      /* RayzTraversal */
-    uint32_t chunk_spp;      /* samples summed per work item, 0 = 16; part of the image's definition
-                                (fixes the f32 summation tree) */
+    uint32_t chunk_spp;      /* samples summed per work item; 0 = the automatic schedule (rayz_hip_chunk_schedule);
+                                part of the image's definition (fixes the f32 summation tree) */
     uint32_t tile_rows;      /* rows per shard tile, 0 = 8 */
     uint32_t shard_index;    /* this call renders rows with (row / tile_rows) % shard_count == shard_index */
     uint32_t shard_count;    /* 0 or 1 = whole image */
@@ -178,9 +178,13 @@ uint32_t rayz_hip_abi_version(void);
 /* Number of rows the shard described by `p` owns (= rows of the compact output). */
 uint32_t rayz_hip_shard_rows(const RayzRenderParams* p);
 
-/* samples per work item the render of `p` will use: p->chunk_spp, or the default when that is 0.  Part of the
- * image's definition; independent of the shard fields. */
-uint32_t rayz_hip_chunk_spp(const RayzRenderParams* p);
+/* The chunk schedule the render of `p` will use — which consecutive samples of a pixel are summed by one work item;
+ * the chunk sums are then added in chunk order (it fixes the f32 summation tree, so it is part of the
+ * image's definition; it depends on width, height, samples_per_px and chunk_spp only, never on the shard fields).
+ * Returns the number of chunks n; if `starts` is not NULL, fills starts[0..min(n, capacity-1)] with the first sample
+ * of each chunk and, last, samples_per_px.  chunk_spp = 0 selects the automatic schedule (uniform 16 for small
+ * renders; 256, 256, .., 128, 64, 32, 16, 16 for large ones). */
+uint32_t rayz_hip_chunk_schedule(const RayzRenderParams* p, uint32_t* starts, uint32_t capacity);
 
 /* Replaces src/renderer.zig:76-78 (initHittables + BVH build) and what follows it: validates the
  * handles (RAYZ_ERR_BAD_ARG for an index out of range, a checker chain that contains a cycle or nests deeper than

@@ -41,6 +41,7 @@ def load() -> C.CDLL:
         "rayz_oracle_render_b_f32": (C.c_int, [S, Cm, Pm, _P(C.c_uint32), C.c_uint32, C.c_void_p, St, C.c_int]),
         "rayz_oracle_render_b_f64": (C.c_int, [S, Cm, Pm, _P(C.c_uint32), C.c_uint32, C.c_void_p, St, C.c_int]),
         "rayz_oracle_shard_rows": (C.c_uint32, [Pm]),
+        "rayz_oracle_chunk_schedule": (C.c_uint32, [Pm, _P(C.c_uint32), C.c_uint32]),
         "rayz_oracle_kat_b": (C.c_int, [C.c_uint32, C.c_uint32, _D, C.c_uint32, _D]),
         "rayz_oracle_kat_a": (C.c_int, [C.c_uint32, _D, C.c_uint32, _D]),
         "rayz_oracle_filter_audit": (C.c_int, [S, Cm, Pm, C.c_uint32, _P(C.c_uint32), C.c_uint32, _U64]),

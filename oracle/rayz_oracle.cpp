@@ -1151,6 +1151,38 @@ static PathResult<R> tracePath(const SceneB<R>& sc, const CamB<R>& cam, const Ra
     return res; // depth exhausted → black, src/renderer.zig:104-105
 }
 
+// Chunk schedule, restated: which consecutive samples of a pixel are summed by one work item.
+static std::vector<u32> chunkSchedule(const RayzRenderParams& p) {
+    std::vector<u32> st{0};
+    const u32 spp = p.samples_per_px;
+    if (p.chunk_spp != 0 || (u64)p.width * p.height < (1ull << 19) || spp < 64) {
+        const u32 c = p.chunk_spp ? p.chunk_spp : 16;
+        for (u64 s0 = c; s0 < spp; s0 += c) st.push_back((u32)s0);
+        st.push_back(spp);
+        return st;
+    }
+    auto pow2floor = [](u32 v) {
+        u32 r = 1;
+        while (2 * (u64)r <= v) r *= 2;
+        return r;
+    };
+    u32 C = pow2floor(spp / 2);
+    if (C > 256) C = 256;
+    u32 at = 0, rem = spp;
+    while (rem >= 2 * C) {
+        at += C, rem -= C;
+        st.push_back(at);
+    }
+    while (rem > 16) {
+        u32 c = pow2floor(rem / 2);
+        if (c < 16) c = 16;
+        at += c, rem -= c;
+        st.push_back(at);
+    }
+    if (rem) st.push_back(at + rem);
+    return st;
+}
+
 static inline u32 shardRows(const RayzRenderParams& p, std::vector<u32>* rows) {
     const u32 tr = p.tile_rows ? p.tile_rows : 8;
     const u32 sc = p.shard_count ? p.shard_count : 1;
@@ -1172,7 +1204,7 @@ static int render(const RayzSceneDesc* sd, const RayzCameraDesc* cd, const RayzR
     SceneB<R> sc = buildScene<R>(*sd, originBound(*sd, cd));
     if (useBvh(*pp, sd->n_spheres + sd->n_triangles)) buildBvh<R>(*sd, sc);
     const CamB<R> cam = buildCamera<R>(*cd);
-    const u32 C = p.chunk_spp ? p.chunk_spp : 16;
+    const std::vector<u32> chunks = chunkSchedule(p);
     std::vector<u32> pixels; // global pixel indices, in output order
     if (pixel_list) pixels.assign(pixel_list, pixel_list + n_list);
     else {
@@ -1190,8 +1222,8 @@ static int render(const RayzSceneDesc* sd, const RayzCameraDesc* cd, const RayzR
     for (long k = 0; k < np; ++k) {
         const u32 px = pixels[k] % p.width, py = pixels[k] / p.width;
         V<R> pix{0, 0, 0};
-        for (u32 s0 = 0; s0 < p.samples_per_px; s0 += C) {
-            const u32 s1 = std::min(p.samples_per_px, s0 + C);
+        for (size_t c = 0; c + 1 < chunks.size(); ++c) {
+            const u32 s0 = chunks[c], s1 = chunks[c + 1];
             V<R> acc{0, 0, 0};
             for (u32 s = s0; s < s1; ++s) {
                 const PathResult<R> r = tracePath<R>(sc, cam, p, px, py, s);
@@ -1263,6 +1295,11 @@ int rayz_oracle_render_b_f64(const RayzSceneDesc* s, const RayzCameraDesc* c, co
     return B::render<double>(s, c, p, pixel_list, n_list, out, st, threads);
 }
 uint32_t rayz_oracle_shard_rows(const RayzRenderParams* p) { return B::shardRows(*p, nullptr); }
+uint32_t rayz_oracle_chunk_schedule(const RayzRenderParams* p, uint32_t* starts, uint32_t capacity) {
+    const std::vector<u32> v = B::chunkSchedule(*p);
+    for (size_t i = 0; starts && i < v.size() && i < capacity; ++i) starts[i] = v[i];
+    return (uint32_t)v.size() - 1;
+}
 
 // ---- known answers: the pieces of mode B (kernel arithmetic) and of mode A (the reference as written) on the record
 // formats of rayz_hip_kat (include/rayz_hip.h: RayzKatOp, RAYZ_KAT_IN_STRIDE / RAYZ_KAT_OUT_STRIDE) ---------------------

@@ -88,7 +88,7 @@ PROTOTYPES = [
     ("rayz_hip_last_error", C.c_char_p, []),
     ("rayz_hip_abi_version", C.c_uint32, []),
     ("rayz_hip_shard_rows", C.c_uint32, [C.POINTER(RenderParams)]),
-    ("rayz_hip_chunk_spp", C.c_uint32, [C.POINTER(RenderParams)]),
+    ("rayz_hip_chunk_schedule", C.c_uint32, [C.POINTER(RenderParams), C.POINTER(C.c_uint32), C.c_uint32]),
     ("rayz_hip_scene_create", C.c_int, [C.POINTER(SceneDesc), C.POINTER(C.c_void_p)]),
     ("rayz_hip_scene_create_on", C.c_int, [C.c_int, C.POINTER(SceneDesc), C.POINTER(C.c_void_p)]),
     ("rayz_hip_scene_destroy", C.c_int, [C.c_void_p]),

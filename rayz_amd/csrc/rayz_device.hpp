@@ -95,7 +95,8 @@ template <class R> struct TraceArgs {
     unsigned long long seed;
     R tmin;
     uint32_t width, height, spp, max_bounces;
-    uint32_t chunk_spp, chunks_per_px;
+    const uint32_t* chunk_start; // [chunks_per_px + 1] first sample of every chunk of a pixel (the chunk schedule)
+    uint32_t chunks_per_px;
     uint32_t tile_rows, shard_index, shard_count, shard_pixels;
     uint32_t total_items;
     uint32_t bvh_keep;       // BVH kernel: keep_active | keep_stepping << 8 (see trace_kernel_bvh)
@@ -797,8 +798,8 @@ __device__ __forceinline__ void path_refill(PathState<R>& p, const TraceArgs<R>&
             p.px = lp - lr * A.width;
             const uint32_t tl = lr / A.tile_rows, within = lr - tl * A.tile_rows;
             p.py = (tl * A.shard_count + A.shard_index) * A.tile_rows + within;
-            p.s_cur = k * A.chunk_spp;
-            p.s_end = p.s_cur + A.chunk_spp < A.spp ? p.s_cur + A.chunk_spp : A.spp;
+            p.s_cur = A.chunk_start[k];
+            p.s_end = A.chunk_start[k + 1];
             p.acc = {R(0), R(0), R(0)};
         }
         if (base + n_need >= (unsigned long long)A.total_items) queue_empty = true;
@@ -815,11 +816,14 @@ __device__ __forceinline__ void path_refill(PathState<R>& p, const TraceArgs<R>&
 }
 
 // ---- the persistent trace kernel (flat hit list) ----------------------------------------------------------
-// Work item = (pixel of this shard, chunk of ≤chunk_spp consecutive samples).  Items are numbered chunk-major so
+// Work item = (pixel of this shard, chunk k of the pixel's chunk schedule: samples chunk_start[k] .. chunk_start[k+1]).
+// The schedule puts the big chunks first and ends in small ones (host: chunk_schedule), so the queue's tail is made
+// of short items.  Items are numbered chunk-major so
 // that the 64 lanes of a wave start on 64 neighbouring pixels.  Each of a lane's NR slots owns one item at a
 // time, runs its paths one after the other, adds their radiance in sample order, and stores the chunk sum to
 // partial[item]; resolve_kernel adds the chunk sums of a pixel in chunk order.  The summation tree is therefore
-// fixed by (spp, chunk_spp) alone — not by the schedule, the grid size, NR or the number of GPUs.
+// fixed by the chunk schedule alone — a function of (width, height, spp, chunk_spp) — not by the launch, the grid
+// size, NR or the number of GPUs.
 template <class R, int NR> __global__ __launch_bounds__(256, NR == 1 ? 4 : 3) void trace_kernel(const TraceArgs<R> A) {
     const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     PathState<R> p[NR];
@@ -1114,8 +1118,8 @@ template <class R> __global__ __launch_bounds__(256, 5) void trace_kernel_bvh(co
                 px = lp - lr * A.width;
                 const uint32_t tl = lr / A.tile_rows, within = lr - tl * A.tile_rows;
                 py = (tl * A.shard_count + A.shard_index) * A.tile_rows + within;
-                s_cur = k * A.chunk_spp;
-                s_end = s_cur + A.chunk_spp < A.spp ? s_cur + A.chunk_spp : A.spp;
+                s_cur = A.chunk_start[k];
+                s_end = A.chunk_start[k + 1];
                 acc = {R(0), R(0), R(0)};
             }
             if (base + n_need >= (unsigned long long)A.total_items) queue_empty = true;

@@ -157,6 +157,40 @@ struct NarrowBuffers {
 
 uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
 
+// ---- chunk schedule: which samples of a pixel are summed together ------------------------------
+// params.chunk_spp != 0: uniform chunks of that many samples (the last one shorter).  0 = automatic: frames of fewer
+// than 2^19 pixels, or fewer than 64 samples per pixel, use uniform chunks of 16; larger renders use chunks of
+// C = min(256, largest power of two <= spp / 2) while at least 2 C samples remain, and split the rest by halving down
+// to 16 (.. C, C/2, C/4, .., 16, 16): few partial sums per pixel (8 for 1024 spp instead of 64), and the work queue —
+// which hands out chunk 0 of every pixel, then chunk 1, .. — ends in SHORT items, so no lane is left with a long
+// item while the others have run dry.  Depends on the full frame's size, never on the shard: the image is the same
+// for every GPU count.
+void chunk_schedule(const RayzRenderParams* p, std::vector<uint32_t>& starts) {
+    const uint32_t spp = p->samples_per_px;
+    starts.clear();
+    starts.push_back(0);
+    const bool uniform = p->chunk_spp != 0 || (uint64_t)p->width * p->height < (1ull << 19) || spp < 64;
+    if (uniform) {
+        const uint32_t c = p->chunk_spp ? p->chunk_spp : 16u;
+        for (uint64_t s0 = c; s0 < spp; s0 += c) starts.push_back((uint32_t)s0);
+        starts.push_back(spp);
+        return;
+    }
+    auto pow2floor = [](uint32_t v) {
+        uint32_t r = 1;
+        while (r <= v / 2) r *= 2;
+        return r;
+    };
+    const uint32_t C = std::min(256u, pow2floor(spp / 2));
+    uint32_t at = 0, rem = spp;
+    while (rem >= 2 * C) at += C, rem -= C, starts.push_back(at);
+    while (rem > 16) {
+        const uint32_t c = std::max(16u, pow2floor(rem / 2));
+        at += c, rem -= c, starts.push_back(at);
+    }
+    if (rem) starts.push_back(at + rem);
+}
+
 double norm3(const double* v) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
 
 // ---- conservative reject filter ---------------------------------------------------------------
@@ -190,6 +224,9 @@ struct RayzScene {
     bool bvh_built = false;
     void* partial = nullptr; // chunk sums, grow-only
     size_t partial_bytes = 0;
+    uint32_t* chunk_start = nullptr; // device copy of the chunk schedule of the last render
+    size_t chunk_start_cap = 0;
+    std::vector<uint32_t> chunk_start_host;
     unsigned long long* counters = nullptr; // [0] queue head, [1] segments
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipStream_t last_stream = nullptr;
@@ -526,6 +563,8 @@ int validate_params(const RayzRenderParams* p) {
     const uint32_t sc = p->shard_count ? p->shard_count : 1;
     if (p->shard_index >= sc) return fail(RAYZ_ERR_BAD_ARG, "shard_index %u >= shard_count %u", p->shard_index, sc);
     if (!(p->tmin == p->tmin)) return fail(RAYZ_ERR_BAD_ARG, "tmin is NaN");
+    if (p->chunk_spp && (p->samples_per_px - 1) / p->chunk_spp >= (1u << 20))
+        return fail(RAYZ_ERR_BAD_ARG, "more than 2^20 chunks per pixel: raise chunk_spp");
     return RAYZ_OK;
 }
 
@@ -598,8 +637,9 @@ int render_impl(RayzScene* s, const DeviceCtx& ctx, SceneBuffers<R>& b, const Ra
 
     const uint32_t rows = rayz_hip_shard_rows(p);
     const uint64_t shard_pixels64 = (uint64_t)rows * p->width;
-    const uint32_t chunk = rayz_hip_chunk_spp(p);
-    const uint32_t chunks_per_px = (p->samples_per_px + chunk - 1) / chunk;
+    std::vector<uint32_t> starts;
+    chunk_schedule(p, starts);
+    const uint32_t chunks_per_px = (uint32_t)starts.size() - 1;
     const uint64_t items64 = shard_pixels64 * chunks_per_px;
     if (shard_pixels64 >= (1ull << 31) || items64 >= (1ull << 32) - (1ull << 26))
         return fail(RAYZ_ERR_BAD_ARG, "too many work items (%llu): raise chunk_spp", (unsigned long long)items64);
@@ -627,6 +667,18 @@ int render_impl(RayzScene* s, const DeviceCtx& ctx, SceneBuffers<R>& b, const Ra
         s->partial_bytes = need;
     }
     if (!s->counters) HIP_TRY(hipMalloc((void**)&s->counters, 16 * sizeof(unsigned long long)));
+    if (starts != s->chunk_start_host) { // the schedule table, kept on the device until it changes
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (starts.size() > s->chunk_start_cap) {
+            (void)hipFree(s->chunk_start);
+            s->chunk_start = nullptr;
+            s->chunk_start_cap = 0;
+            HIP_TRY(hipMalloc((void**)&s->chunk_start, starts.size() * sizeof(uint32_t)));
+            s->chunk_start_cap = starts.size();
+        }
+        HIP_TRY(hipMemcpy(s->chunk_start, starts.data(), starts.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        s->chunk_start_host = starts;
+    }
     if (!s->ev0) {
         HIP_TRY(hipEventCreate(&s->ev0));
         HIP_TRY(hipEventCreate(&s->ev1));
@@ -662,7 +714,7 @@ int render_impl(RayzScene* s, const DeviceCtx& ctx, SceneBuffers<R>& b, const Ra
     A.height = p->height;
     A.spp = p->samples_per_px;
     A.max_bounces = p->max_bounces;
-    A.chunk_spp = chunk;
+    A.chunk_start = s->chunk_start;
     A.chunks_per_px = chunks_per_px;
     A.tile_rows = p->tile_rows ? p->tile_rows : 8u;
     A.shard_index = p->shard_index;
@@ -794,6 +846,7 @@ int scene_free(RayzScene* s) {
         s->narrow.release();
         (void)hipFree(s->partial);
         (void)hipFree(s->counters);
+        (void)hipFree(s->chunk_start);
         if (s->ev0) (void)hipEventDestroy(s->ev0);
         if (s->ev1) (void)hipEventDestroy(s->ev1);
     }
@@ -981,7 +1034,6 @@ int multi_render(RayzMulti* m, const RayzCameraDesc* cam, const RayzRenderParams
         return fail(RAYZ_ERR_BAD_ARG, "the multi-device entry shards the frame itself: shard_index / shard_count must be 0");
     const uint32_t n = (uint32_t)m->devices.size();
     RayzRenderParams q = *p;
-    q.chunk_spp = rayz_hip_chunk_spp(p); // resolved on the WHOLE frame: the image must not depend on the device count
     q.tile_rows = p->tile_rows ? p->tile_rows : 1u; // pure row interleave balances best
     q.shard_count = n;
     uint32_t max_rows = 0;
@@ -1130,9 +1182,17 @@ uint32_t rayz_hip_shard_rows(const RayzRenderParams* p) {
     return n;
 }
 
-uint32_t rayz_hip_chunk_spp(const RayzRenderParams* p) {
-    if (!p) return 0;
-    return p->chunk_spp ? p->chunk_spp : 16u;
+uint32_t rayz_hip_chunk_schedule(const RayzRenderParams* p, uint32_t* starts, uint32_t capacity) {
+    if (!p || !p->samples_per_px || !p->width || !p->height) return 0;
+    std::vector<uint32_t> v;
+    try {
+        chunk_schedule(p, v);
+    } catch (...) {
+        return 0;
+    }
+    if (starts)
+        for (size_t i = 0; i < v.size() && i < capacity; ++i) starts[i] = v[i];
+    return (uint32_t)v.size() - 1;
 }
 
 int rayz_hip_scene_create(const RayzSceneDesc* scene, RayzScene** out) {

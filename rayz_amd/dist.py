@@ -30,14 +30,23 @@ def max_shard_rows(height: int, world: int, tile_rows: int = DEFAULT_TILE_ROWS) 
 
 
 class FrameGather:
-    """Pre-allocated buffers + index maps for gathering row-tile shards into the full frame on every rank."""
+    """Pre-allocated buffers + index maps for gathering row-tile shards into the full frame on every rank.
+
+    `dtype=torch.uint8` applies `Image.writePPM`'s per-pixel transform (src/image.zig:35-38: sqrt-gamma, clamp,
+    truncate x*255) to this rank's rows BEFORE the collective — `rayz_hip_tonemap_u8` on the GPU — so the tiles
+    travel as u8, 4x smaller than f32, and the gathered frame is what writePPM prints.  The render still writes f32
+    into `tile`; the u8 copy lives in `tile8`.  `tonemap` replaces the device transform (CPU tests)."""
 
     def __init__(self, height: int, width: int, world: int, rank: int, device, dtype=torch.float32,
-                 tile_rows: int = DEFAULT_TILE_ROWS, group=None):
+                 tile_rows: int = DEFAULT_TILE_ROWS, group=None, tonemap=None):
         self.h, self.w, self.world, self.rank, self.group = height, width, world, rank, group
         self.rows = [render.shard_row_indices(height, tile_rows, r, world) for r in range(world)]
         self.max_rows = max(len(r) for r in self.rows)
-        self.tile = torch.zeros((self.max_rows, width, 3), dtype=dtype, device=device)  # this rank's rows (padded)
+        self.u8 = dtype == torch.uint8
+        self._tonemap = tonemap
+        # this rank's rows (padded) as the render writes them
+        self.tile = torch.zeros((self.max_rows, width, 3), dtype=torch.float32 if self.u8 else dtype, device=device)
+        self.tile8 = torch.zeros((self.max_rows, width, 3), dtype=torch.uint8, device=device) if self.u8 else None
         self.frame = torch.empty((height, width, 3), dtype=dtype, device=device)
         self._idx = [torch.as_tensor(r, device=device, dtype=torch.long) for r in self.rows]
         # concatenated along dim 0 (the form both RCCL and gloo accept); viewed per rank when scattering rows
@@ -50,10 +59,18 @@ class FrameGather:
 
     def gather(self) -> torch.Tensor:
         """all_gather the tiles and un-interleave them; returns the full frame (valid on every rank)."""
+        send = self.tile
+        if self.u8:
+            if self._tonemap is not None:
+                self._tonemap(self.tile, self.tile8)
+            else:  # on the stream the render was queued on (torch's current stream)
+                render.tonemap_u8(self.tile.data_ptr(), self.tile8.data_ptr(), self.max_rows * self.w,
+                                  torch.cuda.current_stream().cuda_stream)
+            send = self.tile8
         if self.world == 1:
-            self.frame.copy_(self.tile[: self.h])
+            self.frame.copy_(send[: self.h])
             return self.frame
-        dist.all_gather_into_tensor(self._gathered, self.tile, group=self.group)
+        dist.all_gather_into_tensor(self._gathered, send, group=self.group)
         parts = self._gathered.view(self.world, self.max_rows, self.w, 3)
         for r in range(self.world):
             self.frame.index_copy_(0, self._idx[r], parts[r, : len(self.rows[r])])

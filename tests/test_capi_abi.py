@@ -227,3 +227,39 @@ def test_errors_are_reported_per_thread(built):
     [x.start() for x in ths]
     [x.join() for x in ths]
     assert seen == {"a": "ok", "b": "ok"}, seen
+
+
+def test_chunk_schedule_properties_and_oracle_agreement(built, oracle):
+    """The chunk schedule is part of the image's definition: product and oracle restate it
+    independently and must agree; it partitions [0, spp), does not depend on the shard, keeps small renders on uniform
+    chunks of 16 (the golden fixtures), and ends large renders in short chunks."""
+    lib, olib = capi.load(), oracle.load()
+
+    def sched(fn, **kw):
+        p = capi.RenderParams(**kw)
+        buf = (C.c_uint32 * 4200)()
+        n = fn(C.byref(p), buf, 4200)
+        return list(buf[: n + 1])
+
+    cases = [dict(width=64, height=36, samples_per_px=8), dict(width=1920, height=1080, samples_per_px=1024),
+             dict(width=1920, height=1080, samples_per_px=256), dict(width=3840, height=2160, samples_per_px=4096),
+             dict(width=1920, height=1080, samples_per_px=1000), dict(width=1920, height=1080, samples_per_px=63),
+             dict(width=1920, height=1080, samples_per_px=64), dict(width=1920, height=1080, samples_per_px=100, chunk_spp=7),
+             dict(width=1920, height=1080, samples_per_px=1), dict(width=724, height=724, samples_per_px=77),
+             dict(width=725, height=724, samples_per_px=77), dict(width=1920, height=1080, samples_per_px=5, chunk_spp=16)]
+    for kw in cases:
+        a, b = sched(lib.rayz_hip_chunk_schedule, **kw), sched(olib.rayz_oracle_chunk_schedule, **kw)
+        spp = kw["samples_per_px"]
+        assert a == b and a[0] == 0 and a[-1] == spp and all(x < y for x, y in zip(a, a[1:])), (kw, a, b)
+        for sc in (2, 8):  # shard fields never matter
+            assert sched(lib.rayz_hip_chunk_schedule, **kw, shard_count=sc, shard_index=1, tile_rows=1) == a
+    assert sched(lib.rayz_hip_chunk_schedule, width=64, height=36, samples_per_px=40) == [0, 16, 32, 40]
+    big = sched(lib.rayz_hip_chunk_schedule, width=1920, height=1080, samples_per_px=1024)
+    assert [y - x for x, y in zip(big, big[1:])] == [256, 256, 256, 128, 64, 32, 16, 16]
+    k4 = sched(lib.rayz_hip_chunk_schedule, width=3840, height=2160, samples_per_px=4096)
+    assert len(k4) - 1 == 20 and k4[-1] - k4[-2] == 16
+    p = capi.RenderParams(width=4, height=4, samples_per_px=1 << 30, chunk_spp=1)
+    t = tracer.threeSpheres(32, seed=1)
+    out = np.zeros((4, 4, 3), dtype=np.float32)
+    rc = lib.rayz_hip_render(C.byref(t.scene_desc()), C.byref(t.camera_desc()), C.byref(p), out.ctypes.data_as(C.c_void_p), None)
+    assert rc == capi.ERR_BAD_ARG and b"chunks per pixel" in lib.rayz_hip_last_error()

@@ -13,6 +13,50 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _worker_u8(rank, world, port, q):
+    """The u8 form of the gather: each rank tone-maps ITS rows before the collective (on the GPU:
+    rayz_hip_tonemap_u8; here the host mirror's Image.to_u8 stands in), the gathered frame equals Image.to_u8()."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import binding as oracle
+        from rayz_amd import dist as rdist
+        from rayz_amd import tracer
+
+        t = tracer.randomBouncing(40, -2, 2, seed=5)
+        t.samples_per_px, t.max_bounces = 3, 6
+        t.set_gpu(render_seed=8)
+        sd, cam, p = t.scene_desc(), t.camera_desc(), t.params()
+
+        def to_u8(src, dst):
+            img = tracer.Image(src.shape[0], src.shape[1])
+            img.pixels = src.numpy().astype(np.float64)
+            dst.copy_(torch.from_numpy(img.to_u8()))
+
+        fg = rdist.FrameGather(p.height, p.width, world, rank, torch.device("cpu"), dtype=torch.uint8, tonemap=to_u8)
+        mine, _ = oracle.render_b(sd, cam, rdist.shard_params(p, rank, world), threads=1)
+        fg.tile[: mine.shape[0]] = torch.from_numpy(mine)
+        frame = fg.gather()
+        assert frame.dtype == torch.uint8 and fg._gathered.dtype == torch.uint8  # u8 is what travelled
+        if rank == 0:
+            full, _ = oracle.render_b(sd, cam, p, threads=1)
+            img = tracer.Image(p.height, p.width)
+            img.pixels = full.astype(np.float64)
+            q.put(bool(np.array_equal(frame.numpy(), img.to_u8())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_u8_gather_equals_image_to_u8_gloo(built):
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = 29500 + (os.getpid() * 11 + 5) % 2000
+    mp.spawn(_worker_u8, args=(2, port, q), nprocs=2, join=True)
+    assert q.get() is True
+
+
 def _worker(rank, world, port, tile_rows, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"

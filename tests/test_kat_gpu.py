@@ -63,13 +63,12 @@ def test_conservative_filter_on_the_device(gpu, oracle):
     rec = K.blank(n)
     c, r = np.array([0.0, -1000.0, 0.0]), 1000.0
     o = c + K.unit(rng.normal(size=(n, 3)) + [0, 2, 0]) * (r * (1 + 10.0 ** rng.uniform(-7, -2, n)))[:, None]
-    # aim at a point on the horizon circle seen from o, moved in or out by up to ~1e-5 of the radius
+    # the tangent cone from o makes the angle asin(r / |o - c|) with the direction to the centre: aim along it, a hair
+    # inside or outside
     up = K.unit(o - c)
     tang = K.unit(np.cross(up, rng.normal(size=(n, 3))))
-    h = np.linalg.norm(o - c, axis=1) - r
-    reach = np.sqrt(2 * r * h + h * h)
-    dip = (h / reach + rng.normal(size=n) * 1e-5)[:, None]  # tangent slope +- a hair
-    d = (tang - up * dip) * rng.uniform(0.5, 2.0, (n, 1))
+    alpha = np.arcsin(r / np.linalg.norm(o - c, axis=1)) + rng.normal(size=n) * 10.0 ** rng.uniform(-9, -2, n)
+    d = (tang * np.sin(alpha)[:, None] - up * np.cos(alpha)[:, None]) * rng.uniform(0.5, 2.0, (n, 1))
     rec[:, 0:3], rec[:, 6] = c, r
     rec[:, 7:10], rec[:, 10:13] = K.f32r(o), K.f32r(d)
     rec[:, 13], rec[:, 14], rec[:, 15] = 0.5, 1e-3, np.inf
@@ -78,4 +77,7 @@ def test_conservative_filter_on_the_device(gpu, oracle):
     hit = a[:, 0] == 1
     assert 0.2 < hit.mean() < 0.8  # the set straddles the tangent
     assert (g[hit, 9] == 1).all(), int((g[hit, 9] == 0).sum())
-    assert ((g[:, 9] == 1) & ~hit).mean() < 0.5  # and the padding is thin: it does not just pass everything
+    # and the padding is thin (E = 7.6e-3 on this sphere): a line that misses by more than 2 E is filtered out
+    q, dd = c - rec[:, 7:10], K.unit(rec[:, 10:13])
+    miss = np.linalg.norm(q - (q * dd).sum(1, keepdims=True) * dd, axis=1) - r
+    assert (miss > 0.016).sum() > 1000 and (g[miss > 0.016, 9] == 0).all()
