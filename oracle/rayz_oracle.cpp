@@ -1035,7 +1035,8 @@ template <class R> static bool boxHit(const R* lo, const R* hi, V<R> inv, V<R> o
 
 // RAYZ_TRAVERSAL_AUTO (include/rayz_hip.h): flat list up to RAYZ_AUTO_BVH_MIN hittables, BVH above
 static inline bool useBvh(const RayzRenderParams& p, u32 n_hittables) {
-    return p.traversal == RAYZ_TRAVERSAL_BVH || (p.traversal == RAYZ_TRAVERSAL_AUTO && n_hittables > RAYZ_AUTO_BVH_MIN);
+    return p.traversal == RAYZ_TRAVERSAL_BVH || p.traversal == RAYZ_TRAVERSAL_BVH_WAVEFRONT ||
+           (p.traversal == RAYZ_TRAVERSAL_AUTO && n_hittables > RAYZ_AUTO_BVH_MIN);
 }
 
 template <class R> struct PathResult {

@@ -87,11 +87,34 @@ template <class R> struct DevCamera {
     uint32_t defocus, _pad;
 };
 
+// Path pool of the wavefront form of the BVH traversal: one slot per path in flight, SoA of 16-byte
+// (f32) / 32-byte (f64) records so that the shading pass streams them coalesced.  A slot behaves like a lane of the
+// persistent kernels: it owns one work item at a time and runs its paths one after the other.
+template <class R> struct WfPool {
+    typedef typename VecOf<R>::type r4;
+    r4* ray_o;                 // {o, time}
+    r4* ray_d;                 // {d, -}
+    r4* hit;                   // {tbest, bits(ibest), -, -}: written by the traversal, read by the shading pass
+    ulonglong2* rng;           // PCG32 {state, inc}
+    r4* thr;                   // {throughput, bits(segments so far)}
+    r4* acc;                   // {chunk sum so far, bits(flags: 1 alive | 2 has item)}
+    uint4* work;               // {item, px | py << 16, next sample, end sample}
+    // The pool is cut into n_seg contiguous SEGMENTS of seg_len slots, one per wave of either kernel: the shading
+    // pass's wave w lists the slots of its segment that have a ray at list[w * seg_len ..] and stores how many in
+    // seg_count[w]; the traversal's wave w walks exactly those.  No global atomic is involved (one word takes
+    // ≈88 atomics per µs: a shared list head or fetch cursor would cost milliseconds per pass).
+    uint32_t* list;
+    uint32_t* seg_count;
+    uint32_t n_slots, seg_len, n_seg;
+    uint32_t count_live;       // this pass adds its number of listed rays to counters[4] (the host polls it)
+};
+
 template <class R> struct TraceArgs {
     DevScene<R> sc;
     DevCamera<R> cam;
     typename VecOf<R>::type* partial; // [total_items] chunk sums
-    unsigned long long* counters;     // [0] work-queue head, [1] segments, [2] node tests, [3] sphere tests (BVH)
+    unsigned long long* counters;     // [0] work-queue head, [1] segments, [2] node tests, [3] sphere tests (BVH);
+                                      // wavefront: [4] rays listed by the polled shading passes
     unsigned long long seed;
     R tmin;
     uint32_t width, height, spp, max_bounces;
@@ -100,6 +123,13 @@ template <class R> struct TraceArgs {
     uint32_t tile_rows, shard_index, shard_count, shard_pixels;
     uint32_t total_items;
     uint32_t bvh_keep;       // BVH kernel: keep_active | keep_stepping << 8 (see trace_kernel_bvh)
+};
+
+// the wavefront kernels' arguments: the persistent kernels' + the pool (kept out of TraceArgs so that the persistent
+// kernels' argument block — and with it their scalar-register budget — stays what it was)
+template <class R> struct WfArgs {
+    TraceArgs<R> t;
+    WfPool<R> wf;
 };
 
 // ---- small helpers -----------------------------------------------------------------------------
@@ -115,6 +145,14 @@ __device__ __forceinline__ float ab(float x) { return __builtin_fabsf(x); }
 __device__ __forceinline__ double ab(double x) { return __builtin_fabs(x); }
 __device__ __forceinline__ uint32_t bits(float x) { return __builtin_bit_cast(uint32_t, x); }
 __device__ __forceinline__ uint32_t bits(double x) { return (uint32_t)__builtin_bit_cast(uint64_t, x); }
+
+template <class R> struct Bits; // a u32 carried in the bits of an R
+template <> struct Bits<float> {
+    static __host__ __device__ __forceinline__ float from(uint32_t u) { return __builtin_bit_cast(float, u); }
+};
+template <> struct Bits<double> {
+    static __host__ __device__ __forceinline__ double from(uint32_t u) { return __builtin_bit_cast(double, (uint64_t)u); }
+};
 
 template <class R> struct V {
     R x, y, z;
@@ -1064,7 +1102,10 @@ constexpr int kBvhKeepActive = 24;   // rounds continue while at least this many
 constexpr int kBvhKeepStepping = 12; // phase N continues while at least this many lanes can take a box step
                                      // (defaults; TraceArgs::bvh_keep carries the values in use)
 
-template <class R> __global__ __launch_bounds__(256, 5) void trace_kernel_bvh(const TraceArgs<R> A) {
+#ifndef RAYZ_BVH_WAVES
+#define RAYZ_BVH_WAVES 5
+#endif
+template <class R> __global__ __launch_bounds__(256, RAYZ_BVH_WAVES) void trace_kernel_bvh(const TraceArgs<R> A) {
     typedef typename VecOf<R>::type r4;
     const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     const uint32_t n_nodes = A.sc.bvh_n_nodes;
@@ -1078,8 +1119,10 @@ template <class R> __global__ __launch_bounds__(256, 5) void trace_kernel_bvh(co
     q.ibest = -1;
     q.cur = kBvhDone;
     q.sp = 0;
-    __shared__ uint32_t lds_stack[kBvhStackDepth * 256];
-    uint32_t* stack = lds_stack + threadIdx.x; // entry s of this lane at stack[256 * s]: conflict-free for any mix of s
+    // per-lane traversal stack in LDS, sized by the launch from the tree's depth (dynamic shared memory): entry s of this
+    // lane at stack[256 * s] — conflict-free for any mix of s
+    extern __shared__ uint32_t lds_stack[];
+    uint32_t* stack = lds_stack + threadIdx.x;
     R time = 0;
     uint32_t item = 0, px = 0, py = 0, s_cur = 0, s_end = 0, seg = 0, nseg = 0, node_tests = 0, sphere_tests = 0;
     bool has_item = false, alive = false;
@@ -1225,6 +1268,213 @@ template <class R> __global__ __launch_bounds__(256, 5) void trace_kernel_bvh(co
     }
     if (lane == 0) {
         atomicAdd(&A.counters[1], t0);
+        atomicAdd(&A.counters[2], t1);
+        atomicAdd(&A.counters[3], t2);
+    }
+}
+
+// ---- wavefront form of the BVH traversal -----------------------------------------------------------------------
+// The persistent kernel above keeps a path in ONE lane from camera ray to termination: the f64 roots and the shading
+// inflate its registers (96 VGPRs, 5 waves per SIMD) and a lane that has finished its tree walk idles until enough
+// others have (35 of 64 lanes step on average).  Here the two halves are separate kernels over a pool of paths in
+// HBM: wf_shade_kernel streams the pool (shade the hit, or retire / refill the slot, write the next ray, list the
+// slot) and wf_traverse_kernel only walks the tree — few registers, more waves per SIMD, and idle lanes fetch the
+// next listed ray at once because a fetch is one 32-byte load instead of a shading pass.  Same per-path arithmetic,
+// same RNG streams, same summation tree: images are bit-identical to the persistent kernels'.
+template <class R> __global__ __launch_bounds__(256) void wf_shade_kernel(const WfArgs<R> W) {
+    typedef typename VecOf<R>::type r4;
+    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const TraceArgs<R>& A = W.t;
+    const WfPool<R>& P = W.wf;
+    const uint32_t wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6)); // this wave's segment
+    if (wid >= P.n_seg) return;
+    const uint32_t seg_begin = wid * P.seg_len, seg_end = seg_begin + P.seg_len < P.n_slots ? seg_begin + P.seg_len : P.n_slots;
+    bool queue_empty = false; // wave-uniform
+    uint32_t nseg = 0, n_listed = 0; // n_listed is wave-uniform
+    for (uint32_t base = seg_begin; base < seg_end; base += 64u) {
+        const uint32_t slot = base + lane;
+        const bool valid = slot < seg_end;
+        r4 a4 = valid ? P.acc[slot] : r4{R(0), R(0), R(0), R(0)};
+        const uint32_t flags = bits(a4.w);
+        bool alive = (flags & 1u) != 0u, has_item = (flags & 2u) != 0u;
+        V<R> acc{a4.x, a4.y, a4.z}, o{R(0), R(0), R(0)}, d{R(0), R(0), R(1)}, thr{R(1), R(1), R(1)};
+        R time = R(0);
+        uint32_t seg = 0;
+        Pcg32 g{0, 1};
+        bool dirty = false; // ray / rng / thr records need writing
+        if (alive) { // the traversal has finished this slot's ray: shade it
+            const r4 ro = P.ray_o[slot], rd = P.ray_d[slot], h = P.hit[slot], t4 = P.thr[slot];
+            const ulonglong2 gs = P.rng[slot];
+            o = {ro.x, ro.y, ro.z}, d = {rd.x, rd.y, rd.z}, thr = {t4.x, t4.y, t4.z};
+            time = ro.w;
+            seg = bits(t4.w) + 1u;
+            g = Pcg32{gs.x, gs.y};
+            nseg++;
+            bool cont = shade<R>(A.sc, g, o, d, unit(d), time, h.x, (int)bits(h.y), thr, acc);
+            if (seg >= A.max_bounces) cont = false; // depth exhausted → black, src/renderer.zig:104-105
+            alive = cont;
+            dirty = cont;
+        }
+        if (__ballot(valid && !alive) != 0ull) { // retire finished chunks, refill idle slots, start their next path
+            uint4 w = (valid && !alive && has_item) ? P.work[slot] : uint4{0u, 0u, 0u, 0u};
+            if (valid && !alive && has_item && w.z == w.w) {
+                A.partial[w.x] = r4{acc.x, acc.y, acc.z, R(0)};
+                has_item = false;
+            }
+            const bool need = valid && !alive && !has_item && !queue_empty;
+            const unsigned long long need_mask = __ballot(need);
+            if (need_mask != 0ull) {
+                const uint32_t n_need = (uint32_t)__popcll(need_mask);
+                const int leader = __ffsll((long long)need_mask) - 1;
+                unsigned long long qb = 0;
+                if ((int)lane == leader) qb = atomicAdd(&A.counters[0], (unsigned long long)n_need);
+                qb = __shfl(qb, leader);
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need_mask >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)need_mask, 0u));
+                const unsigned long long mine = qb + rank;
+                if (need && mine < (unsigned long long)A.total_items) {
+                    const uint32_t item = (uint32_t)mine;
+                    const uint32_t k = item / A.shard_pixels, lp = item - k * A.shard_pixels;
+                    const uint32_t lr = lp / A.width, px = lp - lr * A.width;
+                    const uint32_t tl = lr / A.tile_rows, within = lr - tl * A.tile_rows;
+                    const uint32_t py = (tl * A.shard_count + A.shard_index) * A.tile_rows + within;
+                    w = uint4{item, px | (py << 16), A.chunk_start[k], A.chunk_start[k + 1]};
+                    has_item = true;
+                    acc = {R(0), R(0), R(0)};
+                }
+                if (qb + n_need >= (unsigned long long)A.total_items) queue_empty = true;
+            }
+            if (valid && !alive && has_item) { // next path of this slot's chunk
+                const uint32_t px = w.y & 0xffffu, py = w.y >> 16;
+                const unsigned long long pixel_index = (unsigned long long)py * A.width + px;
+                g.seed_path(A.seed, pixel_index * A.spp + w.z);
+                camera_ray<R>(A.cam, g, px, py, o, d, time);
+                thr = {R(1), R(1), R(1)};
+                seg = 0;
+                w.z++;
+                alive = true;
+                dirty = true;
+                P.work[slot] = w;
+            }
+        }
+        if (valid) {
+            if (dirty) {
+                P.ray_o[slot] = r4{o.x, o.y, o.z, time};
+                P.ray_d[slot] = r4{d.x, d.y, d.z, R(0)};
+                P.thr[slot] = r4{thr.x, thr.y, thr.z, Bits<R>::from(seg)};
+                P.rng[slot] = ulonglong2{g.state, g.inc};
+            }
+            const uint32_t nf = (alive ? 1u : 0u) | (has_item ? 2u : 0u);
+            if (nf != flags || nf != 0u) P.acc[slot] = r4{acc.x, acc.y, acc.z, Bits<R>::from(nf)};
+        }
+        // list the slots that have a ray to traverse, compacted by prefix rank inside the wave's own segment
+        const unsigned long long live = __ballot(valid && alive);
+        if (live != 0ull) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0u));
+            if (valid && alive) P.list[seg_begin + n_listed + rank] = slot;
+            n_listed += (uint32_t)__popcll(live);
+        }
+    }
+    if (lane == 0) {
+        P.seg_count[wid] = n_listed;
+        if (P.count_live && n_listed) atomicAdd(&A.counters[4], (unsigned long long)n_listed);
+    }
+    unsigned long long tot = nseg;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+    if (lane == 0 && tot) atomicAdd(&A.counters[1], tot);
+}
+
+#ifndef RAYZ_WF_WAVES
+#define RAYZ_WF_WAVES 8
+#endif
+constexpr int kWfRefill = 16; // idle lanes that trigger a fetch of listed rays (scheduling only; bvh_keep bits 16-23 override)
+
+template <class R> __global__ __launch_bounds__(256, RAYZ_WF_WAVES) void wf_traverse_kernel(const WfArgs<R> W) {
+    typedef typename VecOf<R>::type r4;
+    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const TraceArgs<R>& A = W.t;
+    const WfPool<R>& P = W.wf;
+    const uint32_t wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6)); // this wave's segment
+    if (wid >= P.n_seg) return;
+    const uint32_t n_nodes = A.sc.bvh_n_nodes;
+    const uint32_t n_rays = P.seg_count[wid];
+    const uint32_t* list = P.list + (size_t)wid * P.seg_len;
+    uint32_t cursor = 0; // wave-uniform: listed rays handed out so far
+    const int keep_stepping = (int)((A.bvh_keep >> 8) & 0xffu);
+    const int refill = (A.bvh_keep >> 16) & 0xffu ? (int)((A.bvh_keep >> 16) & 0xffu) : kWfRefill;
+    extern __shared__ uint32_t lds_stack[];
+    uint32_t* stack = lds_stack + threadIdx.x;
+    V<R> o{0, 0, 0}, d{0, 0, 1};
+    R time = 0;
+    BvhQuery<R> q;
+    q.inv = {R(1), R(1), R(1)};
+    q.inv_a2 = 1.0;
+    q.tbest = R(0);
+    q.ibest = -1;
+    q.cur = kBvhDone;
+    q.sp = 0;
+    uint32_t slot = 0, node_tests = 0, sphere_tests = 0;
+    bool alive = false;
+
+    for (;;) {
+        // ---- finished lanes hand in their hit; idle lanes take the next listed rays of the segment ----
+        if (alive && q.cur == kBvhDone && q.sp == 0u) {
+            P.hit[slot] = r4{q.tbest, Bits<R>::from((uint32_t)q.ibest), R(0), R(0)};
+            alive = false;
+        }
+        if (cursor < n_rays) {
+            const unsigned long long need_mask = __ballot(!alive);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need_mask >> 32),
+                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)need_mask, 0u));
+            const uint32_t mine = cursor + rank;
+            if (!alive && mine < n_rays) {
+                slot = list[mine];
+                const r4 ro = P.ray_o[slot], rd = P.ray_d[slot];
+                o = {ro.x, ro.y, ro.z}, d = {rd.x, rd.y, rd.z};
+                time = ro.w;
+                alive = true;
+                bvh_begin<R>(q, d, n_nodes);
+            }
+            cursor += (uint32_t)__popcll(need_mask);
+        }
+        if (__ballot(alive) == 0ull) break;
+
+        // ---- rounds of (N) box steps, (L) leaf tests, (C) candidate roots, until enough lanes are idle to refill ----
+        for (;;) {
+            uint32_t leaf = 0, leaf2 = 0;
+            for (;;) { // phase N
+                if (alive && q.cur == kBvhDone && !bvh_slots_full(leaf, leaf2)) bvh_pop<R>(q, leaf, leaf2, stack);
+                const bool can_step = alive && q.cur != kBvhDone && !bvh_slots_full(leaf, leaf2);
+                const int n_can = __popcll(__ballot(can_step));
+                if (n_can == 0) break;
+                if (n_can < keep_stepping && __ballot(leaf != 0u) != 0ull) break;
+                if (can_step) bvh_node_step<R>(A.sc, q, leaf, leaf2, o, A.tmin, stack, node_tests);
+            }
+            if (__ballot(leaf != 0u) == 0ull) break; // nobody parked: every walking lane ran out of nodes
+            uint32_t cand0 = 0, cand1 = 0;
+            if (leaf != 0u) { // phase L
+                const V<R> ud = unit(d);
+                sphere_tests += leaf & 3u;
+                cand0 = bvh_leaf_entry<R>(A.sc, q, leaf, 0u, o, d, ud, time, A.tmin);
+                if ((leaf & 3u) > 1u) cand1 = bvh_leaf_entry<R>(A.sc, q, leaf, 1u, o, d, ud, time, A.tmin);
+            }
+            if (__ballot((cand0 | cand1) != 0u) != 0ull) { // phase C
+                if (cand0 != 0u) bvh_candidate<R>(A.sc, q, cand0 - 1u, o, d, time, A.tmin);
+                if (cand1 != 0u) bvh_candidate<R>(A.sc, q, cand1 - 1u, o, d, time, A.tmin);
+            }
+            const int n_walking = __popcll(__ballot(alive && (q.cur != kBvhDone || q.sp != 0u)));
+            if (n_walking == 0) break;
+            if (cursor < n_rays && 64 - n_walking >= refill) break; // enough idle lanes: hand in hits, take rays
+        }
+    }
+    unsigned long long t1 = node_tests, t2 = sphere_tests;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        t1 += __shfl_xor(t1, off);
+        t2 += __shfl_xor(t2, off);
+    }
+    if (lane == 0 && (t1 | t2)) {
         atomicAdd(&A.counters[2], t1);
         atomicAdd(&A.counters[3], t2);
     }

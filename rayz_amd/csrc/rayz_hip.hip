@@ -86,23 +86,6 @@ struct DeviceScope {
                         hipGetErrorString(e_), __FILE__, __LINE__);                                         \
     } while (0)
 
-template <class R> struct Bits;
-template <> struct Bits<float> {
-    static float from(uint32_t u) {
-        float f;
-        std::memcpy(&f, &u, 4);
-        return f;
-    }
-};
-template <> struct Bits<double> {
-    static double from(uint32_t u) {
-        uint64_t w = u;
-        double d;
-        std::memcpy(&d, &w, 8);
-        return d;
-    }
-};
-
 // Device copy of the scene in one precision: scan streams + pool-indexed shading tables.
 template <class R> struct SceneBuffers {
     typedef typename VecOf<R>::type r4;
@@ -222,6 +205,9 @@ struct RayzScene {
     std::vector<uint32_t> cls[3]; // pool indices by velocity class: static, mov-Y, mov-G (pool order inside)
     rayz_bvh::FlatBvh bvh;        // host build of the reference's BVH (lazily, first BVH render / export)
     bool bvh_built = false;
+    void* wf_pool = nullptr; // path pool of the wavefront traversal (one allocation, carved into the SoA arrays), grow-only
+    size_t wf_pool_bytes = 0;
+    unsigned long long* wf_host = nullptr; // pinned: the listed-ray count the launch loop polls
     void* partial = nullptr; // chunk sums, grow-only
     size_t partial_bytes = 0;
     uint32_t* chunk_start = nullptr; // device copy of the chunk schedule of the last render
@@ -559,7 +545,7 @@ int validate_params(const RayzRenderParams* p) {
     if (!p) return fail(RAYZ_ERR_BAD_ARG, "params is null");
     if (!p->width || !p->height || !p->samples_per_px) return fail(RAYZ_ERR_BAD_ARG, "width, height and samples_per_px must be > 0");
     if (p->precision > RAYZ_PRECISION_F64) return fail(RAYZ_ERR_BAD_ARG, "bad precision %u", p->precision);
-    if (p->traversal > RAYZ_TRAVERSAL_AUTO) return fail(RAYZ_ERR_BAD_ARG, "bad traversal %u", p->traversal);
+    if (p->traversal > RAYZ_TRAVERSAL_BVH_WAVEFRONT) return fail(RAYZ_ERR_BAD_ARG, "bad traversal %u", p->traversal);
     const uint32_t sc = p->shard_count ? p->shard_count : 1;
     if (p->shard_index >= sc) return fail(RAYZ_ERR_BAD_ARG, "shard_index %u >= shard_count %u", p->shard_index, sc);
     if (!(p->tmin == p->tmin)) return fail(RAYZ_ERR_BAD_ARG, "tmin is NaN");
@@ -613,6 +599,95 @@ int scene_ctx(RayzScene* s, DeviceCtx** out) {
     return RAYZ_OK;
 }
 
+// Wavefront form of the BVH trace: a pool of paths in HBM, alternately shaded / refilled by
+// wf_shade_kernel (which lists the slots that have a ray) and walked through the tree by wf_traverse_kernel, until no
+// slot lists a ray.  The host only launches and polls the listed-ray count (every kWfPoll iterations, so the queue
+// never runs dry); everything else stays on the device.  Blocks the calling thread until the trace is complete.
+constexpr int kWfPoll = 8;
+template <class R>
+int wavefront_trace(RayzScene* s, const DeviceCtx& ctx, const TraceArgs<R>& targs, uint64_t items, size_t bvh_lds, hipStream_t stream) {
+    typedef typename VecOf<R>::type r4;
+    WfArgs<R> A{};
+    A.t = targs;
+    uint64_t slots64 = 1ull << 23; // 8 Mi paths in flight (≈0.9 GB of pool in f32): launches long enough to amortise their tails
+    if (const char* e = std::getenv("RAYZ_WF_SLOTS")) slots64 = std::strtoull(e, nullptr, 10);
+    slots64 = std::max<uint64_t>(std::min(slots64, items), 256);
+    const uint32_t n_slots = (uint32_t)slots64;
+    // one segment per wave of either kernel: enough waves to fill the chip several times over (the hardware's block
+    // scheduler then balances the load), segments long enough that a traversal wave's tail is a small part of its work
+    uint32_t n_seg = (uint32_t)ctx.num_cu * 32u;
+    uint32_t seg_len = ((n_slots + n_seg - 1) / n_seg + 63u) / 64u * 64u;
+    n_seg = (n_slots + seg_len - 1) / seg_len;
+    const size_t rec = sizeof(r4);
+    const size_t off_ray_o = 0, off_ray_d = off_ray_o + rec * n_slots, off_hit = off_ray_d + rec * n_slots,
+                 off_thr = off_hit + rec * n_slots, off_acc = off_thr + rec * n_slots, off_rng = off_acc + rec * n_slots,
+                 off_work = off_rng + sizeof(ulonglong2) * n_slots, off_list = off_work + sizeof(uint4) * n_slots,
+                 off_cnt = off_list + sizeof(uint32_t) * (size_t)n_seg * seg_len, total = off_cnt + sizeof(uint32_t) * n_seg;
+    if (total > s->wf_pool_bytes) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        (void)hipFree(s->wf_pool);
+        s->wf_pool = nullptr;
+        s->wf_pool_bytes = 0;
+        HIP_TRY(hipMalloc(&s->wf_pool, total));
+        s->wf_pool_bytes = total;
+    }
+    if (!s->wf_host) HIP_TRY(hipHostMalloc((void**)&s->wf_host, 2 * sizeof(unsigned long long), hipHostMallocDefault));
+    char* base = (char*)s->wf_pool;
+    A.wf.ray_o = (r4*)(base + off_ray_o), A.wf.ray_d = (r4*)(base + off_ray_d), A.wf.hit = (r4*)(base + off_hit);
+    A.wf.thr = (r4*)(base + off_thr), A.wf.acc = (r4*)(base + off_acc), A.wf.rng = (ulonglong2*)(base + off_rng);
+    A.wf.work = (uint4*)(base + off_work), A.wf.list = (uint32_t*)(base + off_list), A.wf.seg_count = (uint32_t*)(base + off_cnt);
+    A.wf.n_slots = n_slots, A.wf.seg_len = seg_len, A.wf.n_seg = n_seg;
+    HIP_TRY(hipMemsetAsync(A.wf.acc, 0, rec * n_slots, stream)); // flags 0: every slot idle, no item
+
+    const uint32_t grid = (n_seg + 3) / 4;
+    // RAYZ_WF_TIMING=1 (measurement only): HIP events around every launch, per-kernel totals on stderr
+    const bool timing = std::getenv("RAYZ_WF_TIMING") != nullptr;
+    std::vector<hipEvent_t> tev;
+    HIP_TRY(hipEventRecord(s->ev0, stream));
+    uint32_t iterations = 0;
+    for (uint32_t it = 0;; ++it) {
+        iterations = it + 1;
+        if (timing) {
+            for (int k = 0; k < 3; ++k) {
+                hipEvent_t e;
+                HIP_TRY(hipEventCreate(&e));
+                tev.push_back(e);
+            }
+            HIP_TRY(hipEventRecord(tev[tev.size() - 3], stream));
+        }
+        const bool poll = it % kWfPoll == kWfPoll - 1;
+        A.wf.count_live = poll ? 1u : 0u;
+        if (poll) HIP_TRY(hipMemsetAsync(s->counters + 4, 0, sizeof(unsigned long long), stream));
+        hipLaunchKernelGGL(wf_shade_kernel<R>, dim3(grid), dim3(256), 0, stream, A);
+        HIP_TRY(hipGetLastError());
+        if (poll) HIP_TRY(hipMemcpyAsync(s->wf_host, s->counters + 4, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+        if (timing) HIP_TRY(hipEventRecord(tev[tev.size() - 2], stream));
+        hipLaunchKernelGGL(wf_traverse_kernel<R>, dim3(grid), dim3(256), bvh_lds, stream, A);
+        HIP_TRY(hipGetLastError());
+        if (timing) HIP_TRY(hipEventRecord(tev[tev.size() - 1], stream));
+        if (poll) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            if (s->wf_host[0] == 0ull) break; // the shading pass listed nothing: every path has ended, the queue is empty
+        }
+    }
+    if (timing) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        double t_shade = 0, t_trav = 0, trav_busy = 0;
+        uint32_t busy = 0;
+        for (size_t k = 0; k + 2 < tev.size(); k += 3) {
+            float a = 0, b = 0;
+            (void)hipEventElapsedTime(&a, tev[k], tev[k + 1]);
+            (void)hipEventElapsedTime(&b, tev[k + 1], tev[k + 2]);
+            t_shade += a, t_trav += b;
+            if (b > 0.1f) busy++, trav_busy += b;
+        }
+        for (hipEvent_t e : tev) (void)hipEventDestroy(e);
+        std::fprintf(stderr, "wavefront: %u iterations (%u with a traversal > 0.1 ms, %.1f ms of traversal in those), shading %.1f ms, traversal %.1f ms; "
+                             "%u slots in %u segments of %u\n", iterations, busy, trav_busy, t_shade, t_trav, n_slots, n_seg, seg_len);
+    }
+    return RAYZ_OK;
+}
+
 // Launches one render of `p`'s shard on the scene's device.  The caller has selected that device (DeviceScope).
 // A scene supports ONE render in flight: a second call first waits for the previous one (its workspace and
 // counters are reused).
@@ -620,8 +695,10 @@ template <class R>
 int render_impl(RayzScene* s, const DeviceCtx& ctx, SceneBuffers<R>& b, const RayzCameraDesc* cam, const RayzRenderParams* p,
                 R* d_out, hipStream_t stream) {
     typedef typename VecOf<R>::type r4;
-    const bool use_bvh = p->traversal == RAYZ_TRAVERSAL_BVH ||
+    const bool use_bvh = p->traversal == RAYZ_TRAVERSAL_BVH || p->traversal == RAYZ_TRAVERSAL_BVH_WAVEFRONT ||
                          (p->traversal == RAYZ_TRAVERSAL_AUTO && s->spheres.size() + s->triangles.size() > RAYZ_AUTO_BVH_MIN);
+    // the wavefront form packs pixel coordinates in 16 bits each; larger frames take the persistent kernel
+    const bool wavefront = p->traversal == RAYZ_TRAVERSAL_BVH_WAVEFRONT && p->width < 65536u && p->height < 65536u;
     if (s->spheres.size() + s->triangles.size() >= (1u << 27))
         return fail(RAYZ_ERR_BAD_ARG, "too many hittables for the device layout");
     if (s->last_stream && s->last_stream != stream) HIP_TRY(hipStreamSynchronize(s->last_stream)); // previous render done
@@ -723,14 +800,17 @@ int render_impl(RayzScene* s, const DeviceCtx& ctx, SceneBuffers<R>& b, const Ra
     A.total_items = (uint32_t)items64;
     {
         // scheduling thresholds of the BVH kernel (no effect on results); RAYZ_BVH_KEEP="active,stepping" overrides
-        unsigned ka = kBvhKeepActive, ks = kBvhKeepStepping;
-        if (const char* e = std::getenv("RAYZ_BVH_KEEP")) std::sscanf(e, "%u,%u", &ka, &ks);
-        A.bvh_keep = (ka & 0xffu) | ((ks & 0xffu) << 8);
+        unsigned ka = kBvhKeepActive, ks = kBvhKeepStepping, wr = 0;
+        if (const char* e = std::getenv("RAYZ_BVH_KEEP")) std::sscanf(e, "%u,%u,%u", &ka, &ks, &wr);
+        A.bvh_keep = (ka & 0xffu) | ((ks & 0xffu) << 8) | ((wr & 0xffu) << 16);
     }
 
     const int block = 256;
     int blocks_per_cu = 0;
-    if (use_bvh) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, trace_kernel_bvh<R>, block, 0));
+    // the BVH kernel's LDS stack holds one entry per tree level below the root (nearer child first: the stack never
+    // holds more than one entry per level); sized from THIS tree, so a shallow tree does not cap the occupancy
+    const size_t bvh_lds = use_bvh ? ((size_t)s->bvh.depth + 1) * block * sizeof(uint32_t) : 0;
+    if (use_bvh) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, trace_kernel_bvh<R>, block, bvh_lds));
     else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, trace_kernel<R, 1>, block, 0));
     if (blocks_per_cu < 1) blocks_per_cu = 1;
     uint64_t grid = (uint64_t)ctx.num_cu * blocks_per_cu;
@@ -738,10 +818,15 @@ int render_impl(RayzScene* s, const DeviceCtx& ctx, SceneBuffers<R>& b, const Ra
     if (grid > want) grid = want;
 
     HIP_TRY(hipMemsetAsync(s->counters, 0, 16 * sizeof(unsigned long long), stream));
-    HIP_TRY(hipEventRecord(s->ev0, stream));
-    if (use_bvh) hipLaunchKernelGGL(trace_kernel_bvh<R>, dim3((uint32_t)grid), dim3(block), 0, stream, A);
-    else hipLaunchKernelGGL((trace_kernel<R, 1>), dim3((uint32_t)grid), dim3(block), 0, stream, A);
-    HIP_TRY(hipGetLastError());
+    if (wavefront) {
+        const int rc2 = wavefront_trace<R>(s, ctx, A, items64, bvh_lds, stream);
+        if (rc2 != RAYZ_OK) return rc2;
+    } else {
+        HIP_TRY(hipEventRecord(s->ev0, stream));
+        if (use_bvh) hipLaunchKernelGGL(trace_kernel_bvh<R>, dim3((uint32_t)grid), dim3(block), bvh_lds, stream, A);
+        else hipLaunchKernelGGL((trace_kernel<R, 1>), dim3((uint32_t)grid), dim3(block), 0, stream, A);
+        HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipEventRecord(s->ev1, stream));
     hipLaunchKernelGGL(resolve_kernel<R>, dim3((A.shard_pixels + 255) / 256), dim3(256), 0, stream,
                        (const r4*)s->partial, d_out, A.shard_pixels, chunks_per_px, A.spp);
@@ -847,6 +932,8 @@ int scene_free(RayzScene* s) {
         (void)hipFree(s->partial);
         (void)hipFree(s->counters);
         (void)hipFree(s->chunk_start);
+        (void)hipFree(s->wf_pool);
+        if (s->wf_host) (void)hipHostFree(s->wf_host);
         if (s->ev0) (void)hipEventDestroy(s->ev0);
         if (s->ev1) (void)hipEventDestroy(s->ev1);
     }
