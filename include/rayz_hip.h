@@ -61,9 +61,7 @@ typedef enum RayzPrecision {
 typedef enum RayzTraversal {
     RAYZ_TRAVERSAL_LINEAR = 0, /* flat hit list: every sphere tested per segment (north star) */
     RAYZ_TRAVERSAL_BVH = 1,    /* the reference's accelerator, src/hit.zig:101-217 */
-    RAYZ_TRAVERSAL_AUTO = 2,   /* flat list up to RAYZ_AUTO_BVH_MIN hittables, BVH above (same image either way) */
-    RAYZ_TRAVERSAL_BVH_WAVEFRONT = 3 /* the same BVH walked by a traversal-only kernel over a pool of paths in HBM, shading
-                                  in a second kernel (same image; the render call then blocks until the trace is done) */
+    RAYZ_TRAVERSAL_AUTO = 2    /* flat list up to RAYZ_AUTO_BVH_MIN hittables, BVH above (same image either way) */
 } RayzTraversal;
 #define RAYZ_AUTO_BVH_MIN 768u /* measured crossover on MI355X: tools/crossover.py */
 

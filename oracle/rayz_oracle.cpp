@@ -1022,21 +1022,34 @@ template <class R> static void triAccept(R filt, V<R> v0, V<R> e1, V<R> e2, V<R>
         ibest = prim;
     }
 }
-// slab test, src/hit.zig:70-98, with 1/d hoisted and a 4-ulp slack (never culls a box the f64 narrow phase would hit)
-template <class R> static bool boxHit(const R* lo, const R* hi, V<R> inv, V<R> o, R tmin, R tbest, R& t0) {
+// slab test, src/hit.zig:70-98, with 1/d and −o/d hoisted (one fma per plane) and a relative (1 + 4 ulp) plus absolute
+// (4·u·Σ|o_k / d_k|) slack on the exit side: never culls a box the f64 narrow phase would hit
+template <class R> struct SlabRay {
+    V<R> inv, noi;
+    R eb;
+};
+template <class R> static SlabRay<R> slabRay(V<R> o, V<R> d) {
+    SlabRay<R> s;
+    s.inv = {R(1) / d.x, R(1) / d.y, R(1) / d.z};
+    s.noi = {-(o.x * s.inv.x), -(o.y * s.inv.y), -(o.z * s.inv.z)};
+    auto fa = [](R v) { return std::fabs(v) <= (R)3.0e38 ? std::fabs(v) : R(0); };
+    const R u4 = R(4) * (std::numeric_limits<R>::epsilon() / R(2));
+    s.eb = u4 * ((fa(s.noi.x) + fa(s.noi.y)) + fa(s.noi.z));
+    return s;
+}
+template <class R> static bool boxHit(const R* lo, const R* hi, const SlabRay<R>& s, R tmin, R tbest, R& t0) {
     const R slack = R(1) + R(4) * std::numeric_limits<R>::epsilon();
-    const R ax = (lo[0] - o.x) * inv.x, bx = (hi[0] - o.x) * inv.x;
-    const R ay = (lo[1] - o.y) * inv.y, by = (hi[1] - o.y) * inv.y;
-    const R az = (lo[2] - o.z) * inv.z, bz = (hi[2] - o.z) * inv.z;
+    const R ax = fm(lo[0], s.inv.x, s.noi.x), bx = fm(hi[0], s.inv.x, s.noi.x);
+    const R ay = fm(lo[1], s.inv.y, s.noi.y), by = fm(hi[1], s.inv.y, s.noi.y);
+    const R az = fm(lo[2], s.inv.z, s.noi.z), bz = fm(hi[2], s.inv.z, s.noi.z);
     t0 = std::fmax(std::fmax(std::fmin(ax, bx), std::fmin(ay, by)), std::fmax(std::fmin(az, bz), tmin));
     const R t1 = std::fmin(std::fmin(std::fmax(ax, bx), std::fmax(ay, by)), std::fmin(std::fmax(az, bz), tbest));
-    return t1 * slack >= t0;
+    return fm(t1, slack, s.eb) >= t0;
 }
 
 // RAYZ_TRAVERSAL_AUTO (include/rayz_hip.h): flat list up to RAYZ_AUTO_BVH_MIN hittables, BVH above
 static inline bool useBvh(const RayzRenderParams& p, u32 n_hittables) {
-    return p.traversal == RAYZ_TRAVERSAL_BVH || p.traversal == RAYZ_TRAVERSAL_BVH_WAVEFRONT ||
-           (p.traversal == RAYZ_TRAVERSAL_AUTO && n_hittables > RAYZ_AUTO_BVH_MIN);
+    return p.traversal == RAYZ_TRAVERSAL_BVH || (p.traversal == RAYZ_TRAVERSAL_AUTO && n_hittables > RAYZ_AUTO_BVH_MIN);
 }
 
 template <class R> struct PathResult {
@@ -1098,7 +1111,7 @@ static PathResult<R> tracePath(const SceneB<R>& sc, const CamB<R>& cam, const Ra
         };
         if (useBvh(p, (u32)(sc.sph.size() + sc.tri.size()))) {
             // src/hit.zig:181-216 as a skip-link walk
-            const V<R> inv{R(1) / d.x, R(1) / d.y, R(1) / d.z};
+            const SlabRay<R> slab = slabRay<R>(o, d);
             const u32 nn = (u32)sc.nodes.size();
             u32 idx = 0;
             while (idx < nn) {
@@ -1106,7 +1119,7 @@ static PathResult<R> tracePath(const SceneB<R>& sc, const CamB<R>& cam, const Ra
                 res.node_tests++;
                 R t0;
                 u32 next = nd.skip;
-                if (boxHit<R>(nd.lo, nd.hi, inv, o, tmin, tbest, t0)) {
+                if (boxHit<R>(nd.lo, nd.hi, slab, tmin, tbest, t0)) {
                     if (nd.count == 0) next = idx + 1;
                     for (u32 k = 0; k < nd.count; ++k) {
                         res.sphere_tests++;
@@ -1332,11 +1345,10 @@ template <class R> static void katB(uint32_t op, const double* a, double* r) {
         break;
     }
     case RAYZ_KAT_BOX_HIT: {
-        const V<R> d = v3(9);
-        const V<R> inv{R(1) / d.x, R(1) / d.y, R(1) / d.z};
+        const SlabRay<R> slab = slabRay<R>(v3(6), v3(9));
         const R lo[3] = {(R)a[0], (R)a[1], (R)a[2]}, hi[3] = {(R)a[3], (R)a[4], (R)a[5]};
         R t0;
-        r[0] = boxHit<R>(lo, hi, inv, v3(6), (R)a[12], (R)a[13], t0) ? 1.0 : 0.0;
+        r[0] = boxHit<R>(lo, hi, slab, (R)a[12], (R)a[13], t0) ? 1.0 : 0.0;
         r[1] = (double)t0;
         break;
     }

@@ -30,7 +30,7 @@ TEX_CHECKER, TEX_SOLID = 0, 1
 MAT_DIFFUSE, MAT_METALLIC, MAT_DIELECTRIC = 0, 1, 2
 DIFFUSE_UNIT_SPHERE, DIFFUSE_UNIT_SPHERE_SURFACE, DIFFUSE_HEMISPHERE = 0, 1, 2
 PRECISION_F32, PRECISION_F64 = 0, 1
-TRAVERSAL_LINEAR, TRAVERSAL_BVH, TRAVERSAL_AUTO, TRAVERSAL_BVH_WAVEFRONT = 0, 1, 2, 3
+TRAVERSAL_LINEAR, TRAVERSAL_BVH, TRAVERSAL_AUTO = 0, 1, 2
 
 D3 = C.c_double * 3
 

@@ -68,6 +68,7 @@ struct FlatBvh {
     std::vector<FlatNode> nodes;  // depth-first pre-order
     std::vector<uint32_t> order;  // hittable indices after the in-place sorts, i.e. leaf order
     uint32_t depth = 0;
+    std::vector<uint32_t> big;    // hittables kept OUT of the tree (build(.., peel_oversized = true) only)
 };
 
 namespace detail {
@@ -100,14 +101,40 @@ inline void build(std::vector<Item>& h, size_t si, size_t ei, FlatBvh& out, uint
 }
 } // namespace detail
 
+constexpr size_t kMaxBig = 8;   // oversized hittables kept out of the tree, at most
+constexpr size_t kMinTree = 32; // .. and only while the tree keeps more than this many (small pools are flat-list territory)
+
 // Hittables are numbered spheres first, then triangles (src/ecs.zig:43-51 order, triangles appended).
-inline FlatBvh build(const std::vector<RayzSphere>& spheres, const std::vector<RayzTriangle>& triangles) {
+//
+// peel_oversized = false: the reference's tree, node for node (what rayz_hip_scene_bvh exports and the oracle's
+// independent build is checked against).
+// peel_oversized = true (the tree the GPU walks): the same build over the pool MINUS its oversized hittables — those
+// whose box is longer than a quarter of the box of everything else (at most kMaxBig, largest first).  One such hittable
+// (the r = 1000 ground sphere of randomBouncing, src/rayz.zig:58-74) makes the box of every one of its ~14 ancestors
+// cover the whole scene, so every ray visits them all; kept out of the tree it is tested once per segment instead and
+// the remaining boxes are tight.  The nearest hit does not depend on how the hittables are organised.
+inline FlatBvh build(const std::vector<RayzSphere>& spheres, const std::vector<RayzTriangle>& triangles,
+                     bool peel_oversized = false) {
     FlatBvh out;
     if (spheres.empty() && triangles.empty()) return out;
     std::vector<detail::Item> h(spheres.size() + triangles.size());
     for (size_t i = 0; i < spheres.size(); ++i) h[i] = {sphereBox(spheres[i]), (uint32_t)i};
     for (size_t i = 0; i < triangles.size(); ++i)
         h[spheres.size() + i] = {triangleBox(triangles[i]), (uint32_t)(spheres.size() + i)};
+    if (peel_oversized) {
+        auto extent = [](const Box& b) { return std::fmax(std::fmax(b.hi[0] - b.lo[0], b.hi[1] - b.lo[1]), b.hi[2] - b.lo[2]); };
+        while (out.big.size() < kMaxBig && h.size() > kMinTree) {
+            size_t worst = 0;
+            for (size_t i = 1; i < h.size(); ++i)
+                if (extent(h[i].box) > extent(h[worst].box)) worst = i;
+            Box rest;
+            for (size_t i = 0; i < h.size(); ++i)
+                if (i != worst) rest.enclose(h[i].box);
+            if (!(extent(h[worst].box) > 0.25 * extent(rest))) break;
+            out.big.push_back(h[worst].pool);
+            h.erase(h.begin() + (ptrdiff_t)worst); // keeps pool order among the rest
+        }
+    }
     detail::build(h, 0, h.size(), out, 1);
     out.order.resize(h.size());
     for (size_t i = 0; i < h.size(); ++i) out.order[i] = h[i].pool;

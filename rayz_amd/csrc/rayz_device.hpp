@@ -79,7 +79,10 @@ template <class R> struct DevScene {
     const r4* bvh_leaf;      // [stride * slots] leaf order.  sphere: {c, r²}, {v, bits(hittable)};
                              //                  triangle: {v0, bits(hittable)}, {e1, 0}, {e2, 0}
     const d4* bvh_sph64;     // [2 * slots] leaf order, sphere slots only: {c, r²}, {v, 0}
-    uint32_t bvh_n_nodes, bvh_leaf_stride; // bvh_n_nodes = number of inner-node records (0: empty pool)
+    uint32_t bvh_n_nodes, bvh_leaf_stride; // bvh_n_nodes = number of inner-node records (0: nothing in the tree)
+    // oversized hittables kept out of the tree (bvh_build.hpp), tested once per segment before the walk: up to 4 leaf
+    // descriptors (first << 4 | type1 << 3 | type0 << 2 | count) naming slots after the tree's own in bvh_leaf / bvh_sph64
+    uint32_t bvh_n_big_leaves, bvh_big[4];
 };
 
 template <class R> struct DevCamera {
@@ -87,34 +90,11 @@ template <class R> struct DevCamera {
     uint32_t defocus, _pad;
 };
 
-// Path pool of the wavefront form of the BVH traversal: one slot per path in flight, SoA of 16-byte
-// (f32) / 32-byte (f64) records so that the shading pass streams them coalesced.  A slot behaves like a lane of the
-// persistent kernels: it owns one work item at a time and runs its paths one after the other.
-template <class R> struct WfPool {
-    typedef typename VecOf<R>::type r4;
-    r4* ray_o;                 // {o, time}
-    r4* ray_d;                 // {d, -}
-    r4* hit;                   // {tbest, bits(ibest), -, -}: written by the traversal, read by the shading pass
-    ulonglong2* rng;           // PCG32 {state, inc}
-    r4* thr;                   // {throughput, bits(segments so far)}
-    r4* acc;                   // {chunk sum so far, bits(flags: 1 alive | 2 has item)}
-    uint4* work;               // {item, px | py << 16, next sample, end sample}
-    // The pool is cut into n_seg contiguous SEGMENTS of seg_len slots, one per wave of either kernel: the shading
-    // pass's wave w lists the slots of its segment that have a ray at list[w * seg_len ..] and stores how many in
-    // seg_count[w]; the traversal's wave w walks exactly those.  No global atomic is involved (one word takes
-    // ≈88 atomics per µs: a shared list head or fetch cursor would cost milliseconds per pass).
-    uint32_t* list;
-    uint32_t* seg_count;
-    uint32_t n_slots, seg_len, n_seg;
-    uint32_t count_live;       // this pass adds its number of listed rays to counters[4] (the host polls it)
-};
-
 template <class R> struct TraceArgs {
     DevScene<R> sc;
     DevCamera<R> cam;
     typename VecOf<R>::type* partial; // [total_items] chunk sums
-    unsigned long long* counters;     // [0] work-queue head, [1] segments, [2] node tests, [3] sphere tests (BVH);
-                                      // wavefront: [4] rays listed by the polled shading passes
+    unsigned long long* counters;     // [0] work-queue head, [1] segments, [2] node tests, [3] sphere tests (BVH)
     unsigned long long seed;
     R tmin;
     uint32_t width, height, spp, max_bounces;
@@ -123,13 +103,6 @@ template <class R> struct TraceArgs {
     uint32_t tile_rows, shard_index, shard_count, shard_pixels;
     uint32_t total_items;
     uint32_t bvh_keep;       // BVH kernel: keep_active | keep_stepping << 8 (see trace_kernel_bvh)
-};
-
-// the wavefront kernels' arguments: the persistent kernels' + the pool (kept out of TraceArgs so that the persistent
-// kernels' argument block — and with it their scalar-register budget — stays what it was)
-template <class R> struct WfArgs {
-    TraceArgs<R> t;
-    WfPool<R> wf;
 };
 
 // ---- small helpers -----------------------------------------------------------------------------
@@ -945,6 +918,8 @@ constexpr uint32_t kBvhLeafFlag = 0x80000000u; // stack entry is a parked-leaf d
 
 template <class R> struct BvhQuery {
     V<R> inv;       // 1 / d per component
+    V<R> noi;       // −o · inv per component: a slab distance is ONE fma, t = fm(plane, inv, noi)
+    R eb;           // absolute slack of the slab test: 4·u·Σ|noi_k| (finite components only)
     double inv_a2;  // 1 / (d·d) in f64 for the narrow phase
     R tbest;
     int ibest;      // hittable index
@@ -952,8 +927,15 @@ template <class R> struct BvhQuery {
     uint32_t sp;    // stack height
 };
 
-template <class R> __device__ __forceinline__ void bvh_begin(BvhQuery<R>& q, V<R> d, uint32_t n_inner) {
+template <class R> struct Slack; // relative slack of the slab test: 1 + 4 ulp
+template <> struct Slack<float> { static constexpr float v = 1.0f + 4.0f * 1.1920929e-07f, u4 = 4.0f * 5.9604645e-08f; };
+template <> struct Slack<double> { static constexpr double v = 1.0 + 4.0 * 2.220446049250313e-16, u4 = 4.0 * 1.1102230246251565e-16; };
+
+template <class R> __device__ __forceinline__ R finite_abs(R v) { return ab(v) <= (R)3.0e38 ? ab(v) : R(0); } // 0 for ±inf / NaN
+template <class R> __device__ __forceinline__ void bvh_begin(BvhQuery<R>& q, V<R> o, V<R> d, uint32_t n_inner) {
     q.inv = {R(1) / d.x, R(1) / d.y, R(1) / d.z};
+    q.noi = {-(o.x * q.inv.x), -(o.y * q.inv.y), -(o.z * q.inv.z)};
+    q.eb = Slack<R>::u4 * ((finite_abs(q.noi.x) + finite_abs(q.noi.y)) + finite_abs(q.noi.z));
     const double ddx = d.x, ddy = d.y, ddz = d.z;
     q.inv_a2 = 1.0 / fm(ddz, ddz, fm(ddy, ddy, ddx * ddx));
     q.tbest = (R)__builtin_inff();
@@ -962,53 +944,39 @@ template <class R> __device__ __forceinline__ void bvh_begin(BvhQuery<R>& q, V<R
     q.sp = 0;
 }
 
-template <class R> struct Slack;
-template <> struct Slack<float> { static constexpr float v = 1.0f + 4.0f * 1.1920929e-07f; };
-template <> struct Slack<double> { static constexpr double v = 1.0 + 4.0 * 2.220446049250313e-16; };
-
-// Slab test (AABB.hit, src/hit.zig:70-98) with 1/d hoisted and a 4-ulp slack, so that rounding never culls a
-// box the f64 narrow phase would hit.  Returns the entry distance through `t0`.
+// Slab test (AABB.hit, src/hit.zig:70-98) with 1/d and −o/d hoisted: each plane distance is one fma.  It is
+// CONSERVATIVE — rounding never culls a box the f64 narrow phase would hit: fm(plane, inv, noi) differs from
+// (plane − o)·inv by at most u·(|t| + |o·inv|) (the rounding of noi and of the fma), covered on the exit side by the
+// relative slack 1 + 4 ulp and the absolute slack eb = 4·u·Σ|o_k·inv_k|.  A direction component of 0 makes that axis
+// ±inf or NaN, which min / max then ignore: the axis is not tested (conservative again).  Returns the entry distance
+// through `t0`.
 template <class R>
 __device__ __forceinline__ bool bvh_box_hit(typename VecOf<R>::type lo, typename VecOf<R>::type hi, const BvhQuery<R>& q,
-                                            V<R> o, R tmin, R& t0) {
-    const R ax = (lo.x - o.x) * q.inv.x, bx = (hi.x - o.x) * q.inv.x;
-    const R ay = (lo.y - o.y) * q.inv.y, by = (hi.y - o.y) * q.inv.y;
-    const R az = (lo.z - o.z) * q.inv.z, bz = (hi.z - o.z) * q.inv.z;
+                                            R tmin, R& t0) {
+    const R ax = fm(lo.x, q.inv.x, q.noi.x), bx = fm(hi.x, q.inv.x, q.noi.x);
+    const R ay = fm(lo.y, q.inv.y, q.noi.y), by = fm(hi.y, q.inv.y, q.noi.y);
+    const R az = fm(lo.z, q.inv.z, q.noi.z), bz = fm(hi.z, q.inv.z, q.noi.z);
     t0 = mx(mx(mn(ax, bx), mn(ay, by)), mx(mn(az, bz), tmin));
     const R t1 = mn(mn(mx(ax, bx), mx(ay, by)), mn(mx(az, bz), q.tbest));
-    return t1 * Slack<R>::v >= t0;
+    return fm(t1, Slack<R>::v, q.eb) >= t0;
 }
 
-// A lane parks hit leaves for phase L in `leaf` (and `leaf2` when RAYZ_BVH_LEAF_SLOTS is 2); with no slot free the
-// descriptor goes to the stack.  More slots = lanes keep stepping longer between phases (higher lane utilisation) at
-// the price of a staler tbest (more box tests).
-#ifndef RAYZ_BVH_LEAF_SLOTS
-#define RAYZ_BVH_LEAF_SLOTS 1
-#endif
-__device__ __forceinline__ bool bvh_slots_full(uint32_t leaf, uint32_t leaf2) {
-    return RAYZ_BVH_LEAF_SLOTS == 2 ? leaf2 != 0u : leaf != 0u;
-}
+// Phase N — one step of a lane that holds no parked leaf: fetch an inner node's record, slab-test both children, then
+//   * a hit leaf child is PARKED in `leaf` for phase L (a second hit leaf goes to the stack, flagged),
+//   * hit inner children: continue into the nearer, push the farther — unless a leaf was parked: then the inner child
+//     is pushed as well and the lane waits for phase L,
+//   * nothing to continue with: the caller pops.
+// The three cases exclude each other, so a step pushes at most ONE entry.  `stack` is this lane's column of the
+// workgroup's LDS stack (entry s at stack[s * 256]).
 template <class R>
-__device__ __forceinline__ void bvh_park(uint32_t desc, uint32_t& leaf, uint32_t& leaf2, BvhQuery<R>& q, uint32_t* stack) {
-    if (leaf == 0u) leaf = desc;
-    else if (RAYZ_BVH_LEAF_SLOTS == 2 && leaf2 == 0u) leaf2 = desc;
-    else stack[256 * q.sp++] = desc | kBvhLeafFlag;
-}
-
-// Phase N — one step of a lane: fetch an inner node's record, slab-test both children, then
-//   * a hit leaf child is PARKED in `leaf` for phase L (a second hit leaf goes to the stack),
-//   * hit inner children: continue into the nearer, push the farther,
-//   * nothing to continue with: pop.
-// `stack` is this lane's column of the workgroup's LDS stack (entry s at stack[s * 256]).
-template <class R>
-__device__ __forceinline__ void bvh_node_step(const DevScene<R>& sc, BvhQuery<R>& q, uint32_t& leaf, uint32_t& leaf2, V<R> o,
-                                              R tmin, uint32_t* stack, uint32_t& node_tests) {
+__device__ __forceinline__ void bvh_node_step(const DevScene<R>& sc, BvhQuery<R>& q, uint32_t& leaf, R tmin, uint32_t* stack,
+                                              uint32_t& node_tests) {
     typedef typename VecOf<R>::type r4;
     const r4* p = sc.bvh_nodes + 4 * (size_t)q.cur;
     const r4 llo = p[0], lhi = p[1], rlo = p[2], rhi = p[3];
     node_tests += 2;
     R tl, tr;
-    const bool hl = bvh_box_hit<R>(llo, lhi, q, o, tmin, tl), hr = bvh_box_hit<R>(rlo, rhi, q, o, tmin, tr);
+    const bool hl = bvh_box_hit<R>(llo, lhi, q, tmin, tl), hr = bvh_box_hit<R>(rlo, rhi, q, tmin, tr);
     const uint32_t lleaf = bits(lhi.w), rleaf = bits(rhi.w);
     // inner children to continue with (kBvhDone = none), nearer first
     uint32_t near = (hl && lleaf == 0u) ? bits(llo.w) : kBvhDone;
@@ -1018,27 +986,26 @@ __device__ __forceinline__ void bvh_node_step(const DevScene<R>& sc, BvhQuery<R>
         near = far;
         far = t;
     }
-    if (far != kBvhDone) stack[256 * q.sp++] = far;
-    // leaf children: parked in the lane's free slots (the caller guarantees at least one), the rest on the stack
+    // leaf children that were hit: the first is parked, a second one goes to the stack
     const uint32_t l0 = (hl && lleaf != 0u) ? lleaf : 0u, l1 = (hr && rleaf != 0u) ? rleaf : 0u;
-    if (l0 != 0u) bvh_park(l0, leaf, leaf2, q, stack);
-    if (l1 != 0u) bvh_park(l1, leaf, leaf2, q, stack);
-    if (near != kBvhDone && bvh_slots_full(leaf, leaf2)) { // cannot walk on with every slot taken: defer the inner child too
-        stack[256 * q.sp++] = near;
+    const uint32_t first = l0 != 0u ? l0 : l1, second = l0 != 0u ? l1 : 0u;
+    leaf = first;
+    uint32_t push = far;                                   // (inner, inner): the farther child
+    if (second != 0u) push = second | kBvhLeafFlag;        // (leaf, leaf)
+    if (first != 0u && near != kBvhDone) {                 // (leaf, inner): the lane stops at the leaf; the inner child waits
+        push = near;
         near = kBvhDone;
     }
+    if (push != kBvhDone) stack[256 * q.sp++] = push;
     q.cur = near;
 }
 
-// Pop until an inner node is found (→ q.cur) or a leaf descriptor is found (→ parked in `leaf`) or the stack is empty.
-template <class R>
-__device__ __forceinline__ void bvh_pop(BvhQuery<R>& q, uint32_t& leaf, uint32_t& leaf2, const uint32_t* stack) {
+// Pop: an inner node (→ q.cur), a flagged leaf descriptor (→ parked in `leaf`), or nothing when the stack is empty.
+template <class R> __device__ __forceinline__ void bvh_pop(BvhQuery<R>& q, uint32_t& leaf, const uint32_t* stack) {
     if (q.sp != 0u) {
         const uint32_t e = stack[256 * --q.sp];
-        if (e & kBvhLeafFlag) {
-            if (leaf == 0u) leaf = e & ~kBvhLeafFlag;
-            else leaf2 = e & ~kBvhLeafFlag;
-        } else q.cur = e;
+        if (e & kBvhLeafFlag) leaf = e & ~kBvhLeafFlag;
+        else q.cur = e;
     }
 }
 
@@ -1099,11 +1066,14 @@ __device__ __forceinline__ void bvh_candidate(const DevScene<R>& sc, BvhQuery<R>
 #define RAYZ_STAT_SPILL 0x7fffffffu // tests build with a small value to exercise the spill
 #endif
 constexpr int kBvhKeepActive = 24;   // rounds continue while at least this many lanes still walk
-constexpr int kBvhKeepStepping = 12; // phase N continues while at least this many lanes can take a box step
+constexpr int kBvhKeepStepping = 16; // phase N continues while at least this many lanes can take a box step
                                      // (defaults; TraceArgs::bvh_keep carries the values in use)
 
+// Waves per SIMD the register allocation aims at: 4 (128 VGPRs, nothing spilled).  At 5 (96 VGPRs) the kernel spills 54
+// VGPRs into the box-step loop and is 8 % slower; the box steps are issue-bound, not latency-bound (profiles/r02), so the
+// fifth wave buys nothing.
 #ifndef RAYZ_BVH_WAVES
-#define RAYZ_BVH_WAVES 5
+#define RAYZ_BVH_WAVES 4
 #endif
 template <class R> __global__ __launch_bounds__(256, RAYZ_BVH_WAVES) void trace_kernel_bvh(const TraceArgs<R> A) {
     typedef typename VecOf<R>::type r4;
@@ -1114,6 +1084,8 @@ template <class R> __global__ __launch_bounds__(256, RAYZ_BVH_WAVES) void trace_
     V<R> o{0, 0, 0}, d{0, 0, 1}, ud{0, 0, 1}, thr{1, 1, 1}, acc{0, 0, 0};
     BvhQuery<R> q;
     q.inv = {R(1), R(1), R(1)};
+    q.noi = {R(0), R(0), R(0)};
+    q.eb = R(0);
     q.inv_a2 = 1.0;
     q.tbest = R(0);
     q.ibest = -1;
@@ -1125,10 +1097,10 @@ template <class R> __global__ __launch_bounds__(256, RAYZ_BVH_WAVES) void trace_
     uint32_t* stack = lds_stack + threadIdx.x;
     R time = 0;
     uint32_t item = 0, px = 0, py = 0, s_cur = 0, s_end = 0, seg = 0, nseg = 0, node_tests = 0, sphere_tests = 0;
-    bool has_item = false, alive = false;
+    bool has_item = false, alive = false, fresh = false;
     bool queue_empty = false; // wave-uniform
 #ifdef RAYZ_BVH_PROFILE
-    unsigned long long pt[5] = {0, 0, 0, 0, 0}, pl[7] = {0, 0, 0, 0, 0, 0, 0}, pt0 = __builtin_amdgcn_s_memtime();
+    unsigned long long pt[5] = {0, 0, 0, 0, 0}, pl[7] = {0, 0, 0, 0, 0, 0, 0}, px3[3] = {0, 0, 0}, pt0 = __builtin_amdgcn_s_memtime();
 #define RAYZ_PROF_T(k) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); pt[k] += now_ - pt0; pt0 = now_; }
 #define RAYZ_PROF_L(k, n) { pl[k] += (unsigned long long)(n); pl[k + 1] += 1; }
 #else
@@ -1183,50 +1155,60 @@ template <class R> __global__ __launch_bounds__(256, RAYZ_BVH_WAVES) void trace_
             s_cur++;
             alive = true;
             ud = unit(d);
-            bvh_begin<R>(q, d, n_nodes);
+            bvh_begin<R>(q, o, d, n_nodes);
+            fresh = true;
         }
         if (__ballot(alive) == 0ull) break;
+        // ---- every segment that starts here (camera rays above, scattered rays of the last shading pass) first meets
+        //      the oversized hittables kept out of the tree: the walk then starts with their tbest and culls behind it ----
+        if (A.sc.bvh_n_big_leaves != 0u && __ballot(fresh) != 0ull) {
+            if (fresh) {
+                for (uint32_t k = 0; k < A.sc.bvh_n_big_leaves; ++k) { // wave-uniform trip count
+                    const uint32_t desc = A.sc.bvh_big[k];
+                    sphere_tests += desc & 3u;
+                    const uint32_t c0 = bvh_leaf_entry<R>(A.sc, q, desc, 0u, o, d, ud, time, A.tmin);
+                    const uint32_t c1 = (desc & 3u) > 1u ? bvh_leaf_entry<R>(A.sc, q, desc, 1u, o, d, ud, time, A.tmin) : 0u;
+                    if (c0 != 0u) bvh_candidate<R>(A.sc, q, c0 - 1u, o, d, time, A.tmin);
+                    if (c1 != 0u) bvh_candidate<R>(A.sc, q, c1 - 1u, o, d, time, A.tmin);
+                }
+            }
+        }
+        fresh = false;
         RAYZ_PROF_T(0)
 
         // ---- rounds of (N) box steps, (L) leaf tests, (C) candidate roots ----
         const int n_alive = __popcll(__ballot(alive));
         for (;;) {
-            uint32_t leaf = 0, leaf2 = 0;
+            uint32_t leaf = 0;
             for (;;) { // phase N
                 // a lane with nothing in hand takes its next entry off the stack (an inner node, or a parked leaf)
-                if (alive && q.cur == kBvhDone && !bvh_slots_full(leaf, leaf2)) bvh_pop<R>(q, leaf, leaf2, stack);
-                const bool can_step = alive && q.cur != kBvhDone && !bvh_slots_full(leaf, leaf2);
+                if (alive && q.cur == kBvhDone && leaf == 0u) bvh_pop<R>(q, leaf, stack);
+                const bool can_step = alive && q.cur != kBvhDone && leaf == 0u;
                 const int n_can = __popcll(__ballot(can_step));
                 if (n_can == 0) break;
                 if (n_can < keep_stepping && __ballot(leaf != 0u) != 0ull) break;
                 RAYZ_PROF_L(0, n_can)
-                if (can_step) bvh_node_step<R>(A.sc, q, leaf, leaf2, o, A.tmin, stack, node_tests);
+#ifdef RAYZ_BVH_PROFILE
+                px3[0] += __popcll(__ballot(alive && leaf != 0u));
+                px3[1] += __popcll(__ballot(alive && q.cur == kBvhDone && q.sp == 0u && leaf == 0u));
+                px3[2] += __popcll(__ballot(!alive));
+#endif
+                if (can_step) bvh_node_step<R>(A.sc, q, leaf, A.tmin, stack, node_tests);
             }
             RAYZ_PROF_T(1)
             if (__ballot(leaf != 0u) == 0ull) break; // nobody parked: every walking lane ran out of nodes
             RAYZ_PROF_L(2, __popcll(__ballot(leaf != 0u)))
-            uint32_t cand0 = 0, cand1 = 0, cand2 = 0, cand3 = 0;
+            uint32_t cand0 = 0, cand1 = 0;
             if (leaf != 0u) { // phase L
                 sphere_tests += leaf & 3u;
                 cand0 = bvh_leaf_entry<R>(A.sc, q, leaf, 0u, o, d, ud, time, A.tmin);
                 if ((leaf & 3u) > 1u) cand1 = bvh_leaf_entry<R>(A.sc, q, leaf, 1u, o, d, ud, time, A.tmin);
             }
-            if (RAYZ_BVH_LEAF_SLOTS == 2 && __ballot(leaf2 != 0u) != 0ull) {
-                if (leaf2 != 0u) {
-                    sphere_tests += leaf2 & 3u;
-                    cand2 = bvh_leaf_entry<R>(A.sc, q, leaf2, 0u, o, d, ud, time, A.tmin);
-                    if ((leaf2 & 3u) > 1u) cand3 = bvh_leaf_entry<R>(A.sc, q, leaf2, 1u, o, d, ud, time, A.tmin);
-                }
-            }
             RAYZ_PROF_T(2)
-            if (__ballot((cand0 | cand1 | cand2 | cand3) != 0u) != 0ull) { // phase C
-                RAYZ_PROF_L(4, __popcll(__ballot((cand0 | cand1 | cand2 | cand3) != 0u)))
+            if (__ballot((cand0 | cand1) != 0u) != 0ull) { // phase C
+                RAYZ_PROF_L(4, __popcll(__ballot((cand0 | cand1) != 0u)))
                 if (cand0 != 0u) bvh_candidate<R>(A.sc, q, cand0 - 1u, o, d, time, A.tmin);
                 if (cand1 != 0u) bvh_candidate<R>(A.sc, q, cand1 - 1u, o, d, time, A.tmin);
-                if (RAYZ_BVH_LEAF_SLOTS == 2) {
-                    if (cand2 != 0u) bvh_candidate<R>(A.sc, q, cand2 - 1u, o, d, time, A.tmin);
-                    if (cand3 != 0u) bvh_candidate<R>(A.sc, q, cand3 - 1u, o, d, time, A.tmin);
-                }
             }
             RAYZ_PROF_T(3)
             const int n_walking = __popcll(__ballot(alive && (q.cur != kBvhDone || q.sp != 0u)));
@@ -1247,7 +1229,8 @@ template <class R> __global__ __launch_bounds__(256, RAYZ_BVH_WAVES) void trace_
             alive = cont;
             if (cont) {
                 ud = unit(d);
-                bvh_begin<R>(q, d, n_nodes);
+                bvh_begin<R>(q, o, d, n_nodes);
+                fresh = true;
             }
         }
         RAYZ_PROF_T(4)
@@ -1257,6 +1240,7 @@ template <class R> __global__ __launch_bounds__(256, RAYZ_BVH_WAVES) void trace_
     if (lane == 0) {
         for (int k = 0; k < 5; ++k) atomicAdd(&A.counters[4 + k], pt[k]);
         for (int k = 0; k < 7; ++k) atomicAdd(&A.counters[9 + k], pl[k]);
+        for (int k = 0; k < 3; ++k) atomicAdd(&A.counters[16 + k], px3[k]);
     }
 #endif
     unsigned long long t0 = nseg, t1 = node_tests, t2 = sphere_tests;
@@ -1268,213 +1252,6 @@ template <class R> __global__ __launch_bounds__(256, RAYZ_BVH_WAVES) void trace_
     }
     if (lane == 0) {
         atomicAdd(&A.counters[1], t0);
-        atomicAdd(&A.counters[2], t1);
-        atomicAdd(&A.counters[3], t2);
-    }
-}
-
-// ---- wavefront form of the BVH traversal -----------------------------------------------------------------------
-// The persistent kernel above keeps a path in ONE lane from camera ray to termination: the f64 roots and the shading
-// inflate its registers (96 VGPRs, 5 waves per SIMD) and a lane that has finished its tree walk idles until enough
-// others have (35 of 64 lanes step on average).  Here the two halves are separate kernels over a pool of paths in
-// HBM: wf_shade_kernel streams the pool (shade the hit, or retire / refill the slot, write the next ray, list the
-// slot) and wf_traverse_kernel only walks the tree — few registers, more waves per SIMD, and idle lanes fetch the
-// next listed ray at once because a fetch is one 32-byte load instead of a shading pass.  Same per-path arithmetic,
-// same RNG streams, same summation tree: images are bit-identical to the persistent kernels'.
-template <class R> __global__ __launch_bounds__(256) void wf_shade_kernel(const WfArgs<R> W) {
-    typedef typename VecOf<R>::type r4;
-    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    const TraceArgs<R>& A = W.t;
-    const WfPool<R>& P = W.wf;
-    const uint32_t wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6)); // this wave's segment
-    if (wid >= P.n_seg) return;
-    const uint32_t seg_begin = wid * P.seg_len, seg_end = seg_begin + P.seg_len < P.n_slots ? seg_begin + P.seg_len : P.n_slots;
-    bool queue_empty = false; // wave-uniform
-    uint32_t nseg = 0, n_listed = 0; // n_listed is wave-uniform
-    for (uint32_t base = seg_begin; base < seg_end; base += 64u) {
-        const uint32_t slot = base + lane;
-        const bool valid = slot < seg_end;
-        r4 a4 = valid ? P.acc[slot] : r4{R(0), R(0), R(0), R(0)};
-        const uint32_t flags = bits(a4.w);
-        bool alive = (flags & 1u) != 0u, has_item = (flags & 2u) != 0u;
-        V<R> acc{a4.x, a4.y, a4.z}, o{R(0), R(0), R(0)}, d{R(0), R(0), R(1)}, thr{R(1), R(1), R(1)};
-        R time = R(0);
-        uint32_t seg = 0;
-        Pcg32 g{0, 1};
-        bool dirty = false; // ray / rng / thr records need writing
-        if (alive) { // the traversal has finished this slot's ray: shade it
-            const r4 ro = P.ray_o[slot], rd = P.ray_d[slot], h = P.hit[slot], t4 = P.thr[slot];
-            const ulonglong2 gs = P.rng[slot];
-            o = {ro.x, ro.y, ro.z}, d = {rd.x, rd.y, rd.z}, thr = {t4.x, t4.y, t4.z};
-            time = ro.w;
-            seg = bits(t4.w) + 1u;
-            g = Pcg32{gs.x, gs.y};
-            nseg++;
-            bool cont = shade<R>(A.sc, g, o, d, unit(d), time, h.x, (int)bits(h.y), thr, acc);
-            if (seg >= A.max_bounces) cont = false; // depth exhausted → black, src/renderer.zig:104-105
-            alive = cont;
-            dirty = cont;
-        }
-        if (__ballot(valid && !alive) != 0ull) { // retire finished chunks, refill idle slots, start their next path
-            uint4 w = (valid && !alive && has_item) ? P.work[slot] : uint4{0u, 0u, 0u, 0u};
-            if (valid && !alive && has_item && w.z == w.w) {
-                A.partial[w.x] = r4{acc.x, acc.y, acc.z, R(0)};
-                has_item = false;
-            }
-            const bool need = valid && !alive && !has_item && !queue_empty;
-            const unsigned long long need_mask = __ballot(need);
-            if (need_mask != 0ull) {
-                const uint32_t n_need = (uint32_t)__popcll(need_mask);
-                const int leader = __ffsll((long long)need_mask) - 1;
-                unsigned long long qb = 0;
-                if ((int)lane == leader) qb = atomicAdd(&A.counters[0], (unsigned long long)n_need);
-                qb = __shfl(qb, leader);
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need_mask >> 32),
-                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)need_mask, 0u));
-                const unsigned long long mine = qb + rank;
-                if (need && mine < (unsigned long long)A.total_items) {
-                    const uint32_t item = (uint32_t)mine;
-                    const uint32_t k = item / A.shard_pixels, lp = item - k * A.shard_pixels;
-                    const uint32_t lr = lp / A.width, px = lp - lr * A.width;
-                    const uint32_t tl = lr / A.tile_rows, within = lr - tl * A.tile_rows;
-                    const uint32_t py = (tl * A.shard_count + A.shard_index) * A.tile_rows + within;
-                    w = uint4{item, px | (py << 16), A.chunk_start[k], A.chunk_start[k + 1]};
-                    has_item = true;
-                    acc = {R(0), R(0), R(0)};
-                }
-                if (qb + n_need >= (unsigned long long)A.total_items) queue_empty = true;
-            }
-            if (valid && !alive && has_item) { // next path of this slot's chunk
-                const uint32_t px = w.y & 0xffffu, py = w.y >> 16;
-                const unsigned long long pixel_index = (unsigned long long)py * A.width + px;
-                g.seed_path(A.seed, pixel_index * A.spp + w.z);
-                camera_ray<R>(A.cam, g, px, py, o, d, time);
-                thr = {R(1), R(1), R(1)};
-                seg = 0;
-                w.z++;
-                alive = true;
-                dirty = true;
-                P.work[slot] = w;
-            }
-        }
-        if (valid) {
-            if (dirty) {
-                P.ray_o[slot] = r4{o.x, o.y, o.z, time};
-                P.ray_d[slot] = r4{d.x, d.y, d.z, R(0)};
-                P.thr[slot] = r4{thr.x, thr.y, thr.z, Bits<R>::from(seg)};
-                P.rng[slot] = ulonglong2{g.state, g.inc};
-            }
-            const uint32_t nf = (alive ? 1u : 0u) | (has_item ? 2u : 0u);
-            if (nf != flags || nf != 0u) P.acc[slot] = r4{acc.x, acc.y, acc.z, Bits<R>::from(nf)};
-        }
-        // list the slots that have a ray to traverse, compacted by prefix rank inside the wave's own segment
-        const unsigned long long live = __ballot(valid && alive);
-        if (live != 0ull) {
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0u));
-            if (valid && alive) P.list[seg_begin + n_listed + rank] = slot;
-            n_listed += (uint32_t)__popcll(live);
-        }
-    }
-    if (lane == 0) {
-        P.seg_count[wid] = n_listed;
-        if (P.count_live && n_listed) atomicAdd(&A.counters[4], (unsigned long long)n_listed);
-    }
-    unsigned long long tot = nseg;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
-    if (lane == 0 && tot) atomicAdd(&A.counters[1], tot);
-}
-
-#ifndef RAYZ_WF_WAVES
-#define RAYZ_WF_WAVES 8
-#endif
-constexpr int kWfRefill = 16; // idle lanes that trigger a fetch of listed rays (scheduling only; bvh_keep bits 16-23 override)
-
-template <class R> __global__ __launch_bounds__(256, RAYZ_WF_WAVES) void wf_traverse_kernel(const WfArgs<R> W) {
-    typedef typename VecOf<R>::type r4;
-    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    const TraceArgs<R>& A = W.t;
-    const WfPool<R>& P = W.wf;
-    const uint32_t wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6)); // this wave's segment
-    if (wid >= P.n_seg) return;
-    const uint32_t n_nodes = A.sc.bvh_n_nodes;
-    const uint32_t n_rays = P.seg_count[wid];
-    const uint32_t* list = P.list + (size_t)wid * P.seg_len;
-    uint32_t cursor = 0; // wave-uniform: listed rays handed out so far
-    const int keep_stepping = (int)((A.bvh_keep >> 8) & 0xffu);
-    const int refill = (A.bvh_keep >> 16) & 0xffu ? (int)((A.bvh_keep >> 16) & 0xffu) : kWfRefill;
-    extern __shared__ uint32_t lds_stack[];
-    uint32_t* stack = lds_stack + threadIdx.x;
-    V<R> o{0, 0, 0}, d{0, 0, 1};
-    R time = 0;
-    BvhQuery<R> q;
-    q.inv = {R(1), R(1), R(1)};
-    q.inv_a2 = 1.0;
-    q.tbest = R(0);
-    q.ibest = -1;
-    q.cur = kBvhDone;
-    q.sp = 0;
-    uint32_t slot = 0, node_tests = 0, sphere_tests = 0;
-    bool alive = false;
-
-    for (;;) {
-        // ---- finished lanes hand in their hit; idle lanes take the next listed rays of the segment ----
-        if (alive && q.cur == kBvhDone && q.sp == 0u) {
-            P.hit[slot] = r4{q.tbest, Bits<R>::from((uint32_t)q.ibest), R(0), R(0)};
-            alive = false;
-        }
-        if (cursor < n_rays) {
-            const unsigned long long need_mask = __ballot(!alive);
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need_mask >> 32),
-                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)need_mask, 0u));
-            const uint32_t mine = cursor + rank;
-            if (!alive && mine < n_rays) {
-                slot = list[mine];
-                const r4 ro = P.ray_o[slot], rd = P.ray_d[slot];
-                o = {ro.x, ro.y, ro.z}, d = {rd.x, rd.y, rd.z};
-                time = ro.w;
-                alive = true;
-                bvh_begin<R>(q, d, n_nodes);
-            }
-            cursor += (uint32_t)__popcll(need_mask);
-        }
-        if (__ballot(alive) == 0ull) break;
-
-        // ---- rounds of (N) box steps, (L) leaf tests, (C) candidate roots, until enough lanes are idle to refill ----
-        for (;;) {
-            uint32_t leaf = 0, leaf2 = 0;
-            for (;;) { // phase N
-                if (alive && q.cur == kBvhDone && !bvh_slots_full(leaf, leaf2)) bvh_pop<R>(q, leaf, leaf2, stack);
-                const bool can_step = alive && q.cur != kBvhDone && !bvh_slots_full(leaf, leaf2);
-                const int n_can = __popcll(__ballot(can_step));
-                if (n_can == 0) break;
-                if (n_can < keep_stepping && __ballot(leaf != 0u) != 0ull) break;
-                if (can_step) bvh_node_step<R>(A.sc, q, leaf, leaf2, o, A.tmin, stack, node_tests);
-            }
-            if (__ballot(leaf != 0u) == 0ull) break; // nobody parked: every walking lane ran out of nodes
-            uint32_t cand0 = 0, cand1 = 0;
-            if (leaf != 0u) { // phase L
-                const V<R> ud = unit(d);
-                sphere_tests += leaf & 3u;
-                cand0 = bvh_leaf_entry<R>(A.sc, q, leaf, 0u, o, d, ud, time, A.tmin);
-                if ((leaf & 3u) > 1u) cand1 = bvh_leaf_entry<R>(A.sc, q, leaf, 1u, o, d, ud, time, A.tmin);
-            }
-            if (__ballot((cand0 | cand1) != 0u) != 0ull) { // phase C
-                if (cand0 != 0u) bvh_candidate<R>(A.sc, q, cand0 - 1u, o, d, time, A.tmin);
-                if (cand1 != 0u) bvh_candidate<R>(A.sc, q, cand1 - 1u, o, d, time, A.tmin);
-            }
-            const int n_walking = __popcll(__ballot(alive && (q.cur != kBvhDone || q.sp != 0u)));
-            if (n_walking == 0) break;
-            if (cursor < n_rays && 64 - n_walking >= refill) break; // enough idle lanes: hand in hits, take rays
-        }
-    }
-    unsigned long long t1 = node_tests, t2 = sphere_tests;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        t1 += __shfl_xor(t1, off);
-        t2 += __shfl_xor(t2, off);
-    }
-    if (lane == 0 && (t1 | t2)) {
         atomicAdd(&A.counters[2], t1);
         atomicAdd(&A.counters[3], t2);
     }
@@ -1555,13 +1332,12 @@ template <class R> __global__ __launch_bounds__(64) void kat_kernel(uint32_t op,
         break;
     }
     case 3: { // BOX_HIT: lo(3) hi(3) o(3) d(3) tmin tmax -> hit, t_entry
-        const V<R> d = v3(9);
         BvhQuery<R> q;
-        bvh_begin<R>(q, d, 1u);
+        bvh_begin<R>(q, v3(6), v3(9), 1u);
         q.tbest = (R)a[13];
         R t0;
         const r4 lo = {(R)a[0], (R)a[1], (R)a[2], R(0)}, hi = {(R)a[3], (R)a[4], (R)a[5], R(0)};
-        r[0] = bvh_box_hit<R>(lo, hi, q, v3(6), (R)a[12], t0) ? 1.0 : 0.0;
+        r[0] = bvh_box_hit<R>(lo, hi, q, (R)a[12], t0) ? 1.0 : 0.0;
         r[1] = (double)t0;
         break;
     }

@@ -99,6 +99,7 @@ template <class R> struct SceneBuffers {
     r4* bvh_nodes = nullptr; // BVH traversal only
     r4* bvh_leaf = nullptr;
     uint32_t nt_pad = 0, bvh_leaf_stride = 2, bvh_n_inner = 0;
+    uint32_t n_big_leaves = 0, big_desc[4] = {0, 0, 0, 0};
     double pad_S = 0; // the origin bound S the filter radii of these buffers were padded for
     bool ready = false, bvh_ready = false;
     void release() {
@@ -205,9 +206,8 @@ struct RayzScene {
     std::vector<uint32_t> cls[3]; // pool indices by velocity class: static, mov-Y, mov-G (pool order inside)
     rayz_bvh::FlatBvh bvh;        // host build of the reference's BVH (lazily, first BVH render / export)
     bool bvh_built = false;
-    void* wf_pool = nullptr; // path pool of the wavefront traversal (one allocation, carved into the SoA arrays), grow-only
-    size_t wf_pool_bytes = 0;
-    unsigned long long* wf_host = nullptr; // pinned: the listed-ray count the launch loop polls
+    rayz_bvh::FlatBvh bvh_dev;    // the tree the GPU walks: the same build with the oversized hittables kept out (bvh_build.hpp)
+    bool bvh_dev_built = false;
     void* partial = nullptr; // chunk sums, grow-only
     size_t partial_bytes = 0;
     uint32_t* chunk_start = nullptr; // device copy of the chunk schedule of the last render
@@ -374,14 +374,33 @@ void ensure_bvh(RayzScene* s) {
     }
 }
 
+void ensure_bvh_dev(RayzScene* s) {
+    if (!s->bvh_dev_built) {
+        const char* e = std::getenv("RAYZ_BVH_PEEL"); // RAYZ_BVH_PEEL=0 (measurement only): walk the reference's full tree
+        s->bvh_dev = rayz_bvh::build(s->spheres, s->triangles, !(e && e[0] == '0'));
+        s->bvh_dev_built = true;
+    }
+}
+
 template <class R> int upload_bvh_body(RayzScene* s, SceneBuffers<R>& b) {
     typedef typename VecOf<R>::type r4;
-    ensure_bvh(s);
-    const rayz_bvh::FlatBvh& t = s->bvh;
+    ensure_bvh_dev(s);
+    const rayz_bvh::FlatBvh& t = s->bvh_dev;
     const uint32_t ns = (uint32_t)s->spheres.size();
+    // leaf-order slots: the tree's hittables, then the oversized ones kept out of it
+    std::vector<uint32_t> slots(t.order);
+    slots.insert(slots.end(), t.big.begin(), t.big.end());
+    b.n_big_leaves = 0;
+    for (size_t k = 0; k < t.big.size(); k += 2) {
+        const uint32_t first = (uint32_t)(t.order.size() + k), count = (uint32_t)std::min<size_t>(2, t.big.size() - k);
+        uint32_t desc = (first << 4) | count;
+        for (uint32_t j = 0; j < count; ++j)
+            if (t.big[k + j] >= ns) desc |= 1u << (2 + j);
+        b.big_desc[b.n_big_leaves++] = desc;
+    }
     if (!s->narrow.bvh_ready) {
         std::vector<d4> sph64;
-        for (uint32_t prim : t.order) {
+        for (uint32_t prim : slots) {
             if (prim < ns) {
                 const RayzSphere& q = s->spheres[prim];
                 sph64.push_back(d4{q.center[0], q.center[1], q.center[2], q.radius * q.radius});
@@ -428,8 +447,8 @@ template <class R> int upload_bvh_body(RayzScene* s, SceneBuffers<R>& b) {
                 child(t.nodes[i + 1].skip);   // right child = where the left subtree ends
             }
     }
-    b.bvh_n_inner = n_inner;
-    for (uint32_t prim : t.order) {
+    b.bvh_n_inner = t.nodes.empty() ? 0u : n_inner;
+    for (uint32_t prim : slots) {
         if (prim < ns) {
             const RayzSphere& q = s->spheres[prim];
             leaf.push_back(r4{(R)q.center[0], (R)q.center[1], (R)q.center[2], pad_radius2<R>(q, b.pad_S)});
@@ -545,7 +564,7 @@ int validate_params(const RayzRenderParams* p) {
     if (!p) return fail(RAYZ_ERR_BAD_ARG, "params is null");
     if (!p->width || !p->height || !p->samples_per_px) return fail(RAYZ_ERR_BAD_ARG, "width, height and samples_per_px must be > 0");
     if (p->precision > RAYZ_PRECISION_F64) return fail(RAYZ_ERR_BAD_ARG, "bad precision %u", p->precision);
-    if (p->traversal > RAYZ_TRAVERSAL_BVH_WAVEFRONT) return fail(RAYZ_ERR_BAD_ARG, "bad traversal %u", p->traversal);
+    if (p->traversal > RAYZ_TRAVERSAL_AUTO) return fail(RAYZ_ERR_BAD_ARG, "bad traversal %u", p->traversal);
     const uint32_t sc = p->shard_count ? p->shard_count : 1;
     if (p->shard_index >= sc) return fail(RAYZ_ERR_BAD_ARG, "shard_index %u >= shard_count %u", p->shard_index, sc);
     if (!(p->tmin == p->tmin)) return fail(RAYZ_ERR_BAD_ARG, "tmin is NaN");
@@ -599,95 +618,6 @@ int scene_ctx(RayzScene* s, DeviceCtx** out) {
     return RAYZ_OK;
 }
 
-// Wavefront form of the BVH trace: a pool of paths in HBM, alternately shaded / refilled by
-// wf_shade_kernel (which lists the slots that have a ray) and walked through the tree by wf_traverse_kernel, until no
-// slot lists a ray.  The host only launches and polls the listed-ray count (every kWfPoll iterations, so the queue
-// never runs dry); everything else stays on the device.  Blocks the calling thread until the trace is complete.
-constexpr int kWfPoll = 8;
-template <class R>
-int wavefront_trace(RayzScene* s, const DeviceCtx& ctx, const TraceArgs<R>& targs, uint64_t items, size_t bvh_lds, hipStream_t stream) {
-    typedef typename VecOf<R>::type r4;
-    WfArgs<R> A{};
-    A.t = targs;
-    uint64_t slots64 = 1ull << 23; // 8 Mi paths in flight (≈0.9 GB of pool in f32): launches long enough to amortise their tails
-    if (const char* e = std::getenv("RAYZ_WF_SLOTS")) slots64 = std::strtoull(e, nullptr, 10);
-    slots64 = std::max<uint64_t>(std::min(slots64, items), 256);
-    const uint32_t n_slots = (uint32_t)slots64;
-    // one segment per wave of either kernel: enough waves to fill the chip several times over (the hardware's block
-    // scheduler then balances the load), segments long enough that a traversal wave's tail is a small part of its work
-    uint32_t n_seg = (uint32_t)ctx.num_cu * 32u;
-    uint32_t seg_len = ((n_slots + n_seg - 1) / n_seg + 63u) / 64u * 64u;
-    n_seg = (n_slots + seg_len - 1) / seg_len;
-    const size_t rec = sizeof(r4);
-    const size_t off_ray_o = 0, off_ray_d = off_ray_o + rec * n_slots, off_hit = off_ray_d + rec * n_slots,
-                 off_thr = off_hit + rec * n_slots, off_acc = off_thr + rec * n_slots, off_rng = off_acc + rec * n_slots,
-                 off_work = off_rng + sizeof(ulonglong2) * n_slots, off_list = off_work + sizeof(uint4) * n_slots,
-                 off_cnt = off_list + sizeof(uint32_t) * (size_t)n_seg * seg_len, total = off_cnt + sizeof(uint32_t) * n_seg;
-    if (total > s->wf_pool_bytes) {
-        HIP_TRY(hipStreamSynchronize(stream));
-        (void)hipFree(s->wf_pool);
-        s->wf_pool = nullptr;
-        s->wf_pool_bytes = 0;
-        HIP_TRY(hipMalloc(&s->wf_pool, total));
-        s->wf_pool_bytes = total;
-    }
-    if (!s->wf_host) HIP_TRY(hipHostMalloc((void**)&s->wf_host, 2 * sizeof(unsigned long long), hipHostMallocDefault));
-    char* base = (char*)s->wf_pool;
-    A.wf.ray_o = (r4*)(base + off_ray_o), A.wf.ray_d = (r4*)(base + off_ray_d), A.wf.hit = (r4*)(base + off_hit);
-    A.wf.thr = (r4*)(base + off_thr), A.wf.acc = (r4*)(base + off_acc), A.wf.rng = (ulonglong2*)(base + off_rng);
-    A.wf.work = (uint4*)(base + off_work), A.wf.list = (uint32_t*)(base + off_list), A.wf.seg_count = (uint32_t*)(base + off_cnt);
-    A.wf.n_slots = n_slots, A.wf.seg_len = seg_len, A.wf.n_seg = n_seg;
-    HIP_TRY(hipMemsetAsync(A.wf.acc, 0, rec * n_slots, stream)); // flags 0: every slot idle, no item
-
-    const uint32_t grid = (n_seg + 3) / 4;
-    // RAYZ_WF_TIMING=1 (measurement only): HIP events around every launch, per-kernel totals on stderr
-    const bool timing = std::getenv("RAYZ_WF_TIMING") != nullptr;
-    std::vector<hipEvent_t> tev;
-    HIP_TRY(hipEventRecord(s->ev0, stream));
-    uint32_t iterations = 0;
-    for (uint32_t it = 0;; ++it) {
-        iterations = it + 1;
-        if (timing) {
-            for (int k = 0; k < 3; ++k) {
-                hipEvent_t e;
-                HIP_TRY(hipEventCreate(&e));
-                tev.push_back(e);
-            }
-            HIP_TRY(hipEventRecord(tev[tev.size() - 3], stream));
-        }
-        const bool poll = it % kWfPoll == kWfPoll - 1;
-        A.wf.count_live = poll ? 1u : 0u;
-        if (poll) HIP_TRY(hipMemsetAsync(s->counters + 4, 0, sizeof(unsigned long long), stream));
-        hipLaunchKernelGGL(wf_shade_kernel<R>, dim3(grid), dim3(256), 0, stream, A);
-        HIP_TRY(hipGetLastError());
-        if (poll) HIP_TRY(hipMemcpyAsync(s->wf_host, s->counters + 4, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-        if (timing) HIP_TRY(hipEventRecord(tev[tev.size() - 2], stream));
-        hipLaunchKernelGGL(wf_traverse_kernel<R>, dim3(grid), dim3(256), bvh_lds, stream, A);
-        HIP_TRY(hipGetLastError());
-        if (timing) HIP_TRY(hipEventRecord(tev[tev.size() - 1], stream));
-        if (poll) {
-            HIP_TRY(hipStreamSynchronize(stream));
-            if (s->wf_host[0] == 0ull) break; // the shading pass listed nothing: every path has ended, the queue is empty
-        }
-    }
-    if (timing) {
-        HIP_TRY(hipStreamSynchronize(stream));
-        double t_shade = 0, t_trav = 0, trav_busy = 0;
-        uint32_t busy = 0;
-        for (size_t k = 0; k + 2 < tev.size(); k += 3) {
-            float a = 0, b = 0;
-            (void)hipEventElapsedTime(&a, tev[k], tev[k + 1]);
-            (void)hipEventElapsedTime(&b, tev[k + 1], tev[k + 2]);
-            t_shade += a, t_trav += b;
-            if (b > 0.1f) busy++, trav_busy += b;
-        }
-        for (hipEvent_t e : tev) (void)hipEventDestroy(e);
-        std::fprintf(stderr, "wavefront: %u iterations (%u with a traversal > 0.1 ms, %.1f ms of traversal in those), shading %.1f ms, traversal %.1f ms; "
-                             "%u slots in %u segments of %u\n", iterations, busy, trav_busy, t_shade, t_trav, n_slots, n_seg, seg_len);
-    }
-    return RAYZ_OK;
-}
-
 // Launches one render of `p`'s shard on the scene's device.  The caller has selected that device (DeviceScope).
 // A scene supports ONE render in flight: a second call first waits for the previous one (its workspace and
 // counters are reused).
@@ -695,10 +625,8 @@ template <class R>
 int render_impl(RayzScene* s, const DeviceCtx& ctx, SceneBuffers<R>& b, const RayzCameraDesc* cam, const RayzRenderParams* p,
                 R* d_out, hipStream_t stream) {
     typedef typename VecOf<R>::type r4;
-    const bool use_bvh = p->traversal == RAYZ_TRAVERSAL_BVH || p->traversal == RAYZ_TRAVERSAL_BVH_WAVEFRONT ||
+    const bool use_bvh = p->traversal == RAYZ_TRAVERSAL_BVH ||
                          (p->traversal == RAYZ_TRAVERSAL_AUTO && s->spheres.size() + s->triangles.size() > RAYZ_AUTO_BVH_MIN);
-    // the wavefront form packs pixel coordinates in 16 bits each; larger frames take the persistent kernel
-    const bool wavefront = p->traversal == RAYZ_TRAVERSAL_BVH_WAVEFRONT && p->width < 65536u && p->height < 65536u;
     if (s->spheres.size() + s->triangles.size() >= (1u << 27))
         return fail(RAYZ_ERR_BAD_ARG, "too many hittables for the device layout");
     if (s->last_stream && s->last_stream != stream) HIP_TRY(hipStreamSynchronize(s->last_stream)); // previous render done
@@ -708,8 +636,8 @@ int render_impl(RayzScene* s, const DeviceCtx& ctx, SceneBuffers<R>& b, const Ra
     if (use_bvh) {
         rc = upload_bvh<R>(s, b);
         if (rc != RAYZ_OK) return rc;
-        if (s->bvh.depth > (uint32_t)kBvhStackDepth)
-            return fail(RAYZ_ERR_BAD_ARG, "BVH depth %u exceeds the traversal stack (%d)", s->bvh.depth, kBvhStackDepth);
+        if (s->bvh_dev.depth > (uint32_t)kBvhStackDepth)
+            return fail(RAYZ_ERR_BAD_ARG, "BVH depth %u exceeds the traversal stack (%d)", s->bvh_dev.depth, kBvhStackDepth);
     }
 
     const uint32_t rows = rayz_hip_shard_rows(p);
@@ -743,7 +671,7 @@ int render_impl(RayzScene* s, const DeviceCtx& ctx, SceneBuffers<R>& b, const Ra
         HIP_TRY(hipMalloc(&s->partial, need));
         s->partial_bytes = need;
     }
-    if (!s->counters) HIP_TRY(hipMalloc((void**)&s->counters, 16 * sizeof(unsigned long long)));
+    if (!s->counters) HIP_TRY(hipMalloc((void**)&s->counters, 32 * sizeof(unsigned long long)));
     if (starts != s->chunk_start_host) { // the schedule table, kept on the device until it changes
         HIP_TRY(hipStreamSynchronize(stream));
         if (starts.size() > s->chunk_start_cap) {
@@ -782,6 +710,8 @@ int render_impl(RayzScene* s, const DeviceCtx& ctx, SceneBuffers<R>& b, const Ra
     A.sc.bvh_sph64 = s->narrow.bvh_sph64;
     A.sc.bvh_n_nodes = use_bvh ? b.bvh_n_inner : 0u;
     A.sc.bvh_leaf_stride = b.bvh_leaf_stride;
+    A.sc.bvh_n_big_leaves = use_bvh ? b.n_big_leaves : 0u;
+    for (int k = 0; k < 4; ++k) A.sc.bvh_big[k] = b.big_desc[k];
     fill_camera<R>(cam, A.cam);
     A.partial = (r4*)s->partial;
     A.counters = s->counters;
@@ -800,16 +730,16 @@ int render_impl(RayzScene* s, const DeviceCtx& ctx, SceneBuffers<R>& b, const Ra
     A.total_items = (uint32_t)items64;
     {
         // scheduling thresholds of the BVH kernel (no effect on results); RAYZ_BVH_KEEP="active,stepping" overrides
-        unsigned ka = kBvhKeepActive, ks = kBvhKeepStepping, wr = 0;
-        if (const char* e = std::getenv("RAYZ_BVH_KEEP")) std::sscanf(e, "%u,%u,%u", &ka, &ks, &wr);
-        A.bvh_keep = (ka & 0xffu) | ((ks & 0xffu) << 8) | ((wr & 0xffu) << 16);
+        unsigned ka = kBvhKeepActive, ks = kBvhKeepStepping;
+        if (const char* e = std::getenv("RAYZ_BVH_KEEP")) std::sscanf(e, "%u,%u", &ka, &ks);
+        A.bvh_keep = (ka & 0xffu) | ((ks & 0xffu) << 8);
     }
 
     const int block = 256;
     int blocks_per_cu = 0;
     // the BVH kernel's LDS stack holds one entry per tree level below the root (nearer child first: the stack never
     // holds more than one entry per level); sized from THIS tree, so a shallow tree does not cap the occupancy
-    const size_t bvh_lds = use_bvh ? ((size_t)s->bvh.depth + 1) * block * sizeof(uint32_t) : 0;
+    const size_t bvh_lds = use_bvh ? ((size_t)s->bvh_dev.depth + 1) * block * sizeof(uint32_t) : 0;
     if (use_bvh) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, trace_kernel_bvh<R>, block, bvh_lds));
     else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, trace_kernel<R, 1>, block, 0));
     if (blocks_per_cu < 1) blocks_per_cu = 1;
@@ -817,16 +747,11 @@ int render_impl(RayzScene* s, const DeviceCtx& ctx, SceneBuffers<R>& b, const Ra
     const uint64_t want = (items64 + block - 1) / block;
     if (grid > want) grid = want;
 
-    HIP_TRY(hipMemsetAsync(s->counters, 0, 16 * sizeof(unsigned long long), stream));
-    if (wavefront) {
-        const int rc2 = wavefront_trace<R>(s, ctx, A, items64, bvh_lds, stream);
-        if (rc2 != RAYZ_OK) return rc2;
-    } else {
-        HIP_TRY(hipEventRecord(s->ev0, stream));
-        if (use_bvh) hipLaunchKernelGGL(trace_kernel_bvh<R>, dim3((uint32_t)grid), dim3(block), bvh_lds, stream, A);
-        else hipLaunchKernelGGL((trace_kernel<R, 1>), dim3((uint32_t)grid), dim3(block), 0, stream, A);
-        HIP_TRY(hipGetLastError());
-    }
+    HIP_TRY(hipMemsetAsync(s->counters, 0, 32 * sizeof(unsigned long long), stream));
+    HIP_TRY(hipEventRecord(s->ev0, stream));
+    if (use_bvh) hipLaunchKernelGGL(trace_kernel_bvh<R>, dim3((uint32_t)grid), dim3(block), bvh_lds, stream, A);
+    else hipLaunchKernelGGL((trace_kernel<R, 1>), dim3((uint32_t)grid), dim3(block), 0, stream, A);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev1, stream));
     hipLaunchKernelGGL(resolve_kernel<R>, dim3((A.shard_pixels + 255) / 256), dim3(256), 0, stream,
                        (const r4*)s->partial, d_out, A.shard_pixels, chunks_per_px, A.spp);
@@ -889,7 +814,7 @@ int scene_sync(RayzScene* s, RayzRenderStats* stats) {
     DeviceScope scope(s->device);
     if (s->last_stream) HIP_TRY(hipStreamSynchronize(s->last_stream));
     if (s->rendered) {
-        unsigned long long c[16] = {};
+        unsigned long long c[32] = {};
         HIP_TRY(hipMemcpy(c, s->counters, sizeof(c), hipMemcpyDeviceToHost));
 #ifdef RAYZ_FLAT_PROFILE // measurement build only: wave time per phase of trace_kernel
         if (!s->last_bvh && c[9]) {
@@ -908,6 +833,11 @@ int scene_sync(RayzScene* s, RayzRenderStats* stats) {
                          100.0 * c[4] / tot, 100.0 * c[5] / tot, (double)c[9] / (double)(c[10] ? c[10] : 1), 100.0 * c[6] / tot,
                          (double)c[11] / (double)(c[12] ? c[12] : 1), 100.0 * c[7] / tot, (double)c[13] / (double)(c[14] ? c[14] : 1),
                          100.0 * c[8] / tot, (double)c[1] / (double)(c[15] ? c[15] : 1));
+            const double it = (double)(c[10] ? c[10] : 1);
+            std::fprintf(stderr, "  box steps: lanes per wave-step — stepping %.1f | parked at a leaf %.1f | walk finished, waiting for the shading pass %.1f | "
+                                 "no path %.1f; wave-steps per segment %.2f; shading passes %.3g, rounds %.3g\n",
+                         (double)c[9] / it, (double)c[16] / it, (double)c[17] / it, (double)c[18] / it, it / (double)(c[1] ? c[1] : 1) * 1.0,
+                         (double)c[15], (double)c[12]);
         }
 #endif
         float ms = 0;
@@ -932,8 +862,6 @@ int scene_free(RayzScene* s) {
         (void)hipFree(s->partial);
         (void)hipFree(s->counters);
         (void)hipFree(s->chunk_start);
-        (void)hipFree(s->wf_pool);
-        if (s->wf_host) (void)hipHostFree(s->wf_host);
         if (s->ev0) (void)hipEventDestroy(s->ev0);
         if (s->ev1) (void)hipEventDestroy(s->ev1);
     }

@@ -91,7 +91,7 @@ int rayz_tracer_set_u64(RayzTracer* t, int field, uint64_t v) {
         t->t.gpu.precision = (RayzPrecision)v;
         break;
     case RAYZ_FIELD_TRAVERSAL:
-        if (v > RAYZ_TRAVERSAL_BVH_WAVEFRONT) return RAYZ_ERR_BAD_ARG;
+        if (v > RAYZ_TRAVERSAL_AUTO) return RAYZ_ERR_BAD_ARG;
         t->t.gpu.traversal = (RayzTraversal)v;
         break;
     case RAYZ_FIELD_CHUNK_SPP: t->t.gpu.chunk_spp = (uint32_t)v; break;

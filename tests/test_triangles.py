@@ -63,7 +63,8 @@ def _check_counters(gst, ost):
         assert (gst.node_tests, gst.sphere_tests) == (0, ost.sphere_tests)
         return
     assert 0.3 * ost.node_tests <= gst.node_tests <= 2.0 * ost.node_tests + 64
-    assert 0.3 * ost.sphere_tests <= gst.sphere_tests <= 2.0 * ost.sphere_tests + 64
+    # (+ up to 8 oversized hittables kept out of the GPU's tree and tested once per segment, bvh_build.hpp)
+    assert 0.3 * ost.sphere_tests <= gst.sphere_tests <= 2.0 * ost.sphere_tests + 8 * gst.segments + 64
 
 
 def _pair(gpu, oracle, t):
