@@ -2,6 +2,8 @@ import os
 import sys
 
 import pytest
+import torch  # noqa: F401  (before librayz_hip.so: torch carries its own HIP runtime, and the process must load only one —
+#                the library's libamdhip64 dependency then resolves to the copy torch has already mapped)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
