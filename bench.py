@@ -25,7 +25,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_VALU_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+# FP64 vector peak: half the FP32 figure (64-bit FMA issues every 4 cycles per wave and SIMD).  Not in the local guide;
+# measured with tools/ubench/valu_peak.hip on the whole chip (profiles/r02/valu_peak.jsonl): v_fma_f64 75.1 TFLOP/s,
+# v_pk_fma_f32 140.2, v_fma_f32 121.7 under the clock the chip holds (95.5 % / 89 % / 77 % of the nominal figures).
+PEAK_VALU_F64_TFLOPS = 78.6
 PEAK_HBM_GBPS = 8000.0
+FLOP_PER_BOX_TEST = 24        # trace_kernel_bvh: 6 fma + 6 min/max + two 3-input min/max + the slack fma
 FLOP_PER_TEST_MOVING = 24     # centre-at-time 6 + offset 3 + half_b 5 + c 7 + disc 3
 FLOP_PER_TEST_STATIC = 18
 # what trace_kernel executes per reject test: p1 (2 FMA) + p2 (3 FMA) + r² − p1² − p2² (2 FMA);
@@ -47,9 +52,23 @@ def parse_args():
     ap.add_argument("--traversal", choices=["linear", "bvh"], default="linear")
     ap.add_argument("--precision", choices=["f32", "f64"], default="f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-also", action="store_true", help="skip the extra BVH-traversal frame reported beside the headline")
+    ap.add_argument("--no-also", action="store_true",
+                    help="skip the extra frames reported beside the headline (BVH traversal; f64 fidelity mode, flat list and BVH)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     return ap.parse_args()
+
+
+def kernel_sources_sha256() -> str:
+    """Hash of the files the trace kernels are compiled from (+ the compile flags): ties a committed profile to a build."""
+    import hashlib
+
+    from rayz_amd import _build
+
+    h = hashlib.sha256()
+    for f in ("rayz_amd/csrc/rayz_device.hpp", "rayz_amd/csrc/rayz_hip.hip", "rayz_amd/csrc/bvh_build.hpp", "include/rayz_hip.h"):
+        h.update(open(os.path.join(ROOT, f), "rb").read())
+    h.update(" ".join(_build.HIPFLAGS).encode())
+    return h.hexdigest()
 
 
 def cpu_baseline(t, target_s: float):
@@ -232,22 +251,54 @@ def main():
     if not bool(torch.isfinite(fg.frame).all().item()) or bool((fg.frame < 0).any().item()):
         raise SystemExit("bench.py: the rendered frame holds non-finite or negative radiance")
 
-    # N = 1 only, after the timed region: the same frame through the reference's own accelerator (BVH traversal),
-    # reported beside the headline (which stays the flat hit list BASELINE.json names)
+    # N = 1 only, after the timed region: the same frame through the reference's own accelerator (BVH traversal), and
+    # the f64 fidelity mode (the reference's scalar type and tmin, src/vec.zig:4-8, src/renderer.zig:107) through both —
+    # reported beside the headline, which stays the f32 flat hit list BASELINE.json names.  The f64 frames use fewer
+    # samples per pixel (stated; the rate does not depend on it) so that the default run stays within minutes.
     also = None
-    if world == 1 and args.traversal == "linear" and not args.no_also:
-        t.set_gpu(traversal=capi.TRAVERSAL_BVH)
-        pb = rdist.shard_params(t.params(), rank, world)
-        dscene.render_into(cam, pb, fg.tile.data_ptr(), stream)
-        dscene.sync()
-        t1 = time.perf_counter()
-        dscene.render_into(cam, pb, fg.tile.data_ptr(), stream)
-        stb = dscene.sync()
-        dtb = time.perf_counter() - t1
-        also = {"bvh_traversal": {"value": H * W * args.spp / dtb / 1e6, "unit": "Msamples/s", "ms_per_step": dtb * 1e3,
-                                  "kernel_ms": stb.kernel_ms, "node_tests_per_segment": stb.node_tests / max(stb.segments, 1),
-                                  "sphere_tests_per_segment": stb.sphere_tests / max(stb.segments, 1)}}
-        t.set_gpu(traversal=capi.TRAVERSAL_LINEAR)
+    if world == 1 and args.traversal == "linear" and args.precision == "f32" and not args.no_also:
+        also = {}
+
+        def extra(name, traversal, precision, spp):
+            t.samples_per_px = spp
+            t.set_gpu(traversal=traversal, precision=precision, tmin=1e-10 if precision == capi.PRECISION_F64 else 1e-3)
+            pe = rdist.shard_params(t.params(), rank, world)
+            buf = torch.empty((H, W, 3), dtype=torch.float64 if precision == capi.PRECISION_F64 else torch.float32, device=dev)
+            dscene.render_into(cam, pe, buf.data_ptr(), stream)
+            dscene.sync()
+            t1 = time.perf_counter()
+            dscene.render_into(cam, pe, buf.data_ptr(), stream)
+            st = dscene.sync()
+            dt = time.perf_counter() - t1
+            bvh = traversal == capi.TRAVERSAL_BVH
+            peak_e = PEAK_VALU_F64_TFLOPS if precision == capi.PRECISION_F64 else PEAK_VALU_F32_TFLOPS
+            if bvh:
+                fl = st.node_tests * FLOP_PER_BOX_TEST + st.sphere_tests * FLOP_PER_TEST_MOVING
+            else:
+                fl = st.segments * (n_static_all * EXEC_FLOP_STATIC + n_movy_all * EXEC_FLOP_MOVY + n_movg_all * EXEC_FLOP_MOVG)
+            ach = fl / (st.kernel_ms * 1e-3) / 1e12
+            also[name] = {"value": H * W * spp / dt / 1e6, "unit": "Msamples/s", "spp": spp, "ms_per_step": dt * 1e3,
+                          "kernel_ms": st.kernel_ms, "segments_per_sample": st.segments / st.primary_rays,
+                          "roofline": {"bound": "valu_fp64" if precision == capi.PRECISION_F64 else "valu_fp32",
+                                       "achieved": ach, "peak": peak_e, "unit": "TFLOP/s", "frac": ach / peak_e,
+                                       "kernel": ("trace_kernel_bvh" if bvh else "trace_kernel") +
+                                                 ("<double>" if precision == capi.PRECISION_F64 else "<float>")}}
+            if bvh:
+                also[name]["node_tests_per_segment"] = st.node_tests / max(st.segments, 1)
+                also[name]["sphere_tests_per_segment"] = st.sphere_tests / max(st.segments, 1)
+                also[name]["roofline"]["note"] = (f"per-lane tree walk, issue-bound at 36 of 64 lanes (profiles/r02): priced against the vector "
+                                                  f"peak with {FLOP_PER_BOX_TEST} flop per box test + {FLOP_PER_TEST_MOVING} per leaf test")
+
+        sd0 = scene
+        n_static_all = sum(1 for i in range(sd0.n_spheres) if all(sd0.spheres[i].velocity[k] == 0 for k in range(3)))
+        n_movy_all = sum(1 for i in range(sd0.n_spheres)
+                         if sd0.spheres[i].velocity[1] != 0 and sd0.spheres[i].velocity[0] == 0 and sd0.spheres[i].velocity[2] == 0)
+        n_movg_all = sd0.n_spheres - n_static_all - n_movy_all
+        extra("bvh_traversal", capi.TRAVERSAL_BVH, capi.PRECISION_F32, args.spp)
+        extra("f64_flat_list", capi.TRAVERSAL_LINEAR, capi.PRECISION_F64, max(1, args.spp // 16))
+        extra("f64_bvh_traversal", capi.TRAVERSAL_BVH, capi.PRECISION_F64, max(1, args.spp // 4))
+        t.samples_per_px = args.spp
+        t.set_gpu(traversal=capi.TRAVERSAL_LINEAR, precision=capi.PRECISION_F32, tmin=1e-3)
 
     if rank == 0:
         samples_per_step = H * W * args.spp
@@ -255,8 +306,13 @@ def main():
         sd = scene
         n_moving = sum(1 for i in range(sd.n_spheres) if any(sd.spheres[i].velocity[k] != 0 for k in range(3)))
         n_static = sd.n_spheres - n_moving
-        chunks = (args.spp + 15) // 16
-        hbm_bytes = (H * W / world) * (chunks * 16 * 2 + 12) + 8 * (n_static * 16 + n_moving * 32) * 2.5
+        # compulsory HBM bytes of a frame = the framebuffer write + the scene fetched once per XCD; the
+        # chunk-sum workspace (written by the trace kernel, read back by resolve_kernel) is design traffic, listed apart
+        import ctypes
+
+        n_chunks = capi.load().rayz_hip_chunk_schedule(ctypes.byref(p), None, 0)
+        compulsory_bytes = (H * W / world) * 12 + 8 * (n_static * 16 + n_moving * 32)
+        workspace_bytes = (H * W / world) * n_chunks * 16 * 2
         if args.traversal == "linear":
             # roofline of the dominant kernel (trace_kernel): algorithmic flops of the reject test per launch.
             # With N GPUs each launch covers 1/N of the frame; rank-mean flops over the slowest rank's time.
@@ -273,24 +329,27 @@ def main():
                     "does not execute - that fraction can exceed 1")
         else:
             st_last = dscene.sync()
-            # slab test: 6 sub + 6 mul + 6 min/max + 2 three-way min/max + slack mul = 21 flop; leaf sphere test 24
-            flops = (st_last.node_tests * 21 + st_last.sphere_tests * FLOP_PER_TEST_MOVING)
+            flops = (st_last.node_tests * FLOP_PER_BOX_TEST + st_last.sphere_tests * FLOP_PER_TEST_MOVING)
             executed_flops = flops
             kernel = "trace_kernel_bvh<%s>" % ("double" if args.precision == "f64" else "float")
             note = ("per-lane tree walk: divergence- and latency-bound, priced against the same FP32 vector peak; "
-                    "algorithmic flops = 21 x box tests + 24 x leaf sphere tests")
-        peak = PEAK_VALU_F32_TFLOPS / (2.0 if args.precision == "f64" else 1.0)
+                    f"algorithmic flops = {FLOP_PER_BOX_TEST} x box tests + 24 x leaf sphere tests")
+        peak = PEAK_VALU_F64_TFLOPS if args.precision == "f64" else PEAK_VALU_F32_TFLOPS
         reference_achieved = flops / (kernel_ms_avg * 1e-3) / 1e12   # SURVEY 8d accounting
         achieved = executed_flops / (kernel_ms_avg * 1e-3) / 1e12    # what the kernel executes
-        # HBM bytes per launch from the committed PMC passes of this very command (profiles/), when they exist:
-        # FETCH_SIZE doubled (gfx950 wide-read correction, MI355X_MICROARCH.md) + WRITE_SIZE, KiB -> bytes
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01", "pmc_summary.json")
+        # HBM bytes per launch (FETCH_SIZE doubled — gfx950 wide-read correction, MI355X_MICROARCH.md — plus WRITE_SIZE)
+        # come from rocprofv3 PMC passes of this very command, which cannot run inside this process: they are REPLAYED
+        # from profiles/, and only when the kernel sources hash to what the passes were taken on; otherwise null.
+        traffic, traffic_source = None, None
+        pmc = os.path.join(ROOT, "profiles", "r02", "pmc_summary.json")
         if (os.path.exists(pmc) and world == 1 and args.traversal == "linear" and args.precision == "f32"
                 and (args.width, args.spp, args.grid) == (1920, 1024, 50)):
             try:
                 z = json.load(open(pmc))
-                traffic = (2 * z["r01b_pmc_fetch"]["FETCH_SIZE"] + z["r01b_pmc_write"]["WRITE_SIZE"]) * 1024
+                if z.get("kernel_sources_sha256") == kernel_sources_sha256():
+                    traffic = (2 * z["FETCH_SIZE_KiB"] + z["WRITE_SIZE_KiB"]) * 1024
+                    traffic_source = {"replayed_from": "profiles/r02/pmc_summary.json", "commit": z.get("commit"),
+                                      "kernel_sources_sha256": z.get("kernel_sources_sha256")}
             except Exception:
                 traffic = None
         out = {
@@ -318,9 +377,12 @@ def main():
                 "kernel": kernel, "kernel_ms": kernel_ms_avg, "note": note,
                 "reference_formulation": {"achieved": reference_achieved, "frac": reference_achieved / peak,
                                           "unit": "TFLOP/s"},
-                "hbm": {"algorithmic_bytes": hbm_bytes, "achieved": hbm_bytes / (kernel_ms_avg * 1e-3) / 1e9,
-                        "measured_bytes": traffic,
-                        "measured": None if traffic is None else traffic / (kernel_ms_avg * 1e-3) / 1e9,
+                "traffic_source": traffic_source,
+                "hbm": {"algorithmic_bytes": compulsory_bytes, "achieved": compulsory_bytes / (kernel_ms_avg * 1e-3) / 1e9,
+                        "workspace_bytes": workspace_bytes, "chunk_sums_per_pixel": n_chunks,
+                        "profiled_bytes": traffic,
+                        "profiled_over_algorithmic": None if traffic is None else traffic / compulsory_bytes,
+                        "profiled": None if traffic is None else traffic / (kernel_ms_avg * 1e-3) / 1e9,
                         "peak": PEAK_HBM_GBPS, "unit": "GB/s"},
             },
         }
