@@ -161,7 +161,21 @@ def main():
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        launch_ranks(args)  # does not return
+        launch_ranks(args)  # does not return (the ranks inherit this process's stdout)
+    # stdout carries exactly ONE line, the JSON record: everything else this process (or a library it loads — RCCL prints
+    # a version banner on stdout at its first communicator) writes to fd 1 goes to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        run(args, json_fd)
+    finally:
+        sys.stdout.flush()
+        os.dup2(json_fd, 1)
+        os.close(json_fd)
+
+
+def run(args, json_fd):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -257,7 +271,7 @@ def main():
     # samples per pixel (stated; the rate does not depend on it) so that the default run stays within minutes.
     also = None
     if world == 1 and args.traversal == "linear" and args.precision == "f32" and not args.no_also:
-        also = {}
+        also, frames = {}, {}
 
         def extra(name, traversal, precision, spp):
             t.samples_per_px = spp
@@ -270,6 +284,8 @@ def main():
             dscene.render_into(cam, pe, buf.data_ptr(), stream)
             st = dscene.sync()
             dt = time.perf_counter() - t1
+            if name == "bvh_traversal":
+                frames[name] = buf.cpu().numpy()
             bvh = traversal == capi.TRAVERSAL_BVH
             peak_e = PEAK_VALU_F64_TFLOPS if precision == capi.PRECISION_F64 else PEAK_VALU_F32_TFLOPS
             if bvh:
@@ -298,6 +314,21 @@ def main():
         extra("f64_flat_list", capi.TRAVERSAL_LINEAR, capi.PRECISION_F64, max(1, args.spp // 16))
         extra("f64_bvh_traversal", capi.TRAVERSAL_BVH, capi.PRECISION_F64, max(1, args.spp // 4))
         t.samples_per_px = args.spp
+        # the same frame through the C ABI's one-call multi-device entry (rayz_hip_multi_render: per-device scene, RCCL
+        # gather of the row tiles, un-interleave, copy to HOST memory) on this one device: what a Zig / C caller of the
+        # drop-in gets, PCIe included
+        t.set_gpu(traversal=capi.TRAVERSAL_BVH, precision=capi.PRECISION_F32, tmin=1e-3)
+        ms = render.MultiScene(scene, [local_rank])
+        pm = t.params()
+        ms.render(cam, pm)
+        t1 = time.perf_counter()
+        frame_m, stm = ms.render(cam, pm)
+        dtm = time.perf_counter() - t1
+        also["c_abi_multi_device_entry"] = {
+            "value": H * W * args.spp / dtm / 1e6, "unit": "Msamples/s", "ms_per_step": dtm * 1e3, "kernel_ms": stm.kernel_ms,
+            "devices": 1, "traversal": "bvh", "output": "host memory (PCIe-inclusive)", **ms.info(),
+            "identical_to_device_path": bool(np.array_equal(frame_m, frames["bvh_traversal"]))}
+        ms.close()
         t.set_gpu(traversal=capi.TRAVERSAL_LINEAR, precision=capi.PRECISION_F32, tmin=1e-3)
 
     if rank == 0:
@@ -400,7 +431,8 @@ def main():
             out["also"] = also
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(t, args.cpu_seconds)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
 

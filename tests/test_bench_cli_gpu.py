@@ -19,7 +19,7 @@ def test_bench_json_contract(gpu):
                        timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
+    assert len(lines) == 1 and len(r.stdout.strip().splitlines()) == 1  # ONE line on stdout: library chatter goes to stderr
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -34,7 +34,12 @@ def test_bench_json_contract(gpu):
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["unit"] == "Msamples/s" and cb["value"] > 0 and cb["sample"]
     assert d["value"] > 0 and abs(d["value"] - 96 * 54 * 4 * 2 / (d["ms_per_step"] * 2e-3) / 1e6) < 1e-6 * d["value"] + 1e-9
-    assert d["also"]["bvh_traversal"]["value"] > 0
+    assert d["also"]["bvh_traversal"]["value"] > 0 and d["also"]["bvh_traversal"]["roofline"]["frac"] > 0
+    assert d["also"]["f64_flat_list"]["value"] > 0 and d["also"]["f64_bvh_traversal"]["roofline"]["bound"] == "valu_fp64"
+    m = d["also"]["c_abi_multi_device_entry"]  # rayz_hip_multi_render on one device: RCCL really ran
+    assert m["value"] > 0 and m["n_devices"] == 1 and m["rccl_version"] > 0 and m["identical_to_device_path"] is True
+    hb = d["roofline"]["hbm"]
+    assert hb["algorithmic_bytes"] < hb["workspace_bytes"] * 10 and hb["chunk_sums_per_pixel"] >= 1
 
 
 def test_cli_renders_reference_scene(gpu, tmp_path):
