@@ -184,7 +184,10 @@ template <class R, class G> __device__ __forceinline__ V<R> random_in_unit_spher
         v.x = fm(uniform<R>(g), R(2), R(-1));
         v.y = fm(uniform<R>(g), R(2), R(-1));
         v.z = fm(uniform<R>(g), R(2), R(-1));
-        if (sq(dot3(v, v)) <= R(1)) break;
+        // `v.mag() <= 1` (src/material.zig:199) without the square root: for a correctly rounded sqrt,
+        // sqrt(x) <= 1  <=>  x <= nextafter(1): sqrt(1 + ulp) = 1 + ulp/2 - ulp²/8 lies below the midpoint and rounds to 1,
+        // sqrt(1 + 2 ulp) rounds to 1 + ulp.  Same decision, bit for bit, as the oracle's literal form.
+        if (dot3(v, v) <= (sizeof(R) == 4 ? R(0x1.000002p0f) : R(0x1.0000000000001p0))) break;
     }
     return v;
 }
@@ -1158,13 +1161,16 @@ template <class R> __global__ __launch_bounds__(256, RAYZ_BVH_WAVES) void trace_
             seg = 0;
             s_cur++;
             alive = true;
-            ud = unit(d);
-            bvh_begin<R>(q, o, d, n_nodes);
             fresh = true;
         }
         if (__ballot(alive) == 0ull) break;
-        // ---- every segment that starts here (camera rays above, scattered rays of the last shading pass) first meets
-        //      the oversized hittables kept out of the tree: the walk then starts with their tbest and culls behind it ----
+        // ---- every segment that starts here (camera rays above, scattered rays of the last shading pass): one place
+        //      for the per-segment set-up (unit direction, slab constants) ----
+        if (fresh) {
+            ud = unit(d);
+            bvh_begin<R>(q, o, d, n_nodes);
+        }
+        // .. then the oversized hittables kept out of the tree: the walk starts with their tbest and culls behind it
         if (A.sc.bvh_n_big_leaves != 0u && __ballot(fresh) != 0ull) {
             if (fresh) {
                 for (uint32_t k = 0; k < A.sc.bvh_n_big_leaves; ++k) { // wave-uniform trip count
@@ -1231,11 +1237,9 @@ template <class R> __global__ __launch_bounds__(256, RAYZ_BVH_WAVES) void trace_
             bool cont = shade<R>(A.sc, g, o, d, ud, time, q.tbest, q.ibest, thr, acc);
             if (seg >= A.max_bounces) cont = false;
             alive = cont;
-            if (cont) {
-                ud = unit(d);
-                bvh_begin<R>(q, o, d, n_nodes);
-                fresh = true;
-            }
+            fresh = cont;
+            // until its set-up runs at the top of the loop the lane must not look finished: no node, empty stack, but
+            // `fresh` keeps it out of the next shading pass (the set-up always comes first)
         }
         RAYZ_PROF_T(4)
     }
