@@ -83,6 +83,9 @@ template <class R> struct DevScene {
     // oversized hittables kept out of the tree (bvh_build.hpp), tested once per segment before the walk: up to 4 leaf
     // descriptors (first << 4 | type1 << 3 | type0 << 2 | count) naming slots after the tree's own in bvh_leaf / bvh_sph64
     uint32_t bvh_n_big_leaves, bvh_big[4];
+    // the first bvh_top inner-node records (the top levels of the tree, numbered breadth-first) are copied to LDS by
+    // every workgroup: a quarter of all box steps then read their node in ~100 cycles instead of a global round trip
+    uint32_t bvh_top;
 };
 
 template <class R> struct DevCamera {
@@ -103,6 +106,7 @@ template <class R> struct TraceArgs {
     uint32_t tile_rows, shard_index, shard_count, shard_pixels;
     uint32_t total_items;
     uint32_t bvh_keep;       // BVH kernel: keep_active | keep_stepping << 8 (see trace_kernel_bvh)
+    uint32_t bvh_stack_words; // BVH kernel: u32s of LDS taken by the per-lane stacks (the tree's top follows)
 };
 
 // ---- small helpers -----------------------------------------------------------------------------
@@ -977,10 +981,28 @@ __device__ __forceinline__ bool bvh_box_hit(typename VecOf<R>::type lo, typename
 // workgroup's LDS stack (entry s at stack[s * 256]).
 template <class R>
 __device__ __forceinline__ void bvh_node_step(const DevScene<R>& sc, BvhQuery<R>& q, uint32_t& leaf, R tmin, uint32_t* stack,
-                                              uint32_t& node_tests) {
+                                              uint32_t& node_tests, const typename VecOf<R>::type* top
+#ifdef RAYZ_BVH_PROFILE
+                                              , unsigned long long& g_fetch_ticks
+#endif
+) {
     typedef typename VecOf<R>::type r4;
-    const r4* p = sc.bvh_nodes + 4 * (size_t)q.cur;
-    const r4 llo = p[0], lhi = p[1], rlo = p[2], rhi = p[3];
+    r4 llo, lhi, rlo, rhi;
+#ifdef RAYZ_BVH_PROFILE
+    const unsigned long long tl0 = __builtin_amdgcn_s_memtime();
+#endif
+    if (q.cur < sc.bvh_top) { // top of the tree: from the workgroup's LDS copy
+        const r4* p = top + 4 * (size_t)q.cur;
+        llo = p[0], lhi = p[1], rlo = p[2], rhi = p[3];
+    } else {
+        const r4* p = sc.bvh_nodes + 4 * (size_t)q.cur;
+        llo = p[0], lhi = p[1], rlo = p[2], rhi = p[3];
+    }
+#ifdef RAYZ_BVH_PROFILE // time from issuing the node fetch to having it (the wave's own view), accumulated in g_prof_fetch
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    node_tests += 0u;
+    g_fetch_ticks += __builtin_amdgcn_s_memtime() - tl0;
+#endif
     node_tests += 2;
     R tl, tr;
     const bool hl = bvh_box_hit<R>(llo, lhi, q, tmin, tl), hr = bvh_box_hit<R>(rlo, rhi, q, tmin, tr);
@@ -1102,12 +1124,16 @@ template <class R> __global__ __launch_bounds__(256, RAYZ_BVH_WAVES) void trace_
     // lane at stack[256 * s] — conflict-free for any mix of s
     extern __shared__ uint32_t lds_stack[];
     uint32_t* stack = lds_stack + threadIdx.x;
+    // behind the stacks (A.bvh_stack_words u32s, a multiple of 64 B): the top of the tree, copied once per workgroup
+    r4* top = (r4*)(lds_stack + A.bvh_stack_words);
+    for (uint32_t k = threadIdx.x; k < 4u * A.sc.bvh_top; k += 256u) top[k] = A.sc.bvh_nodes[k];
+    __syncthreads();
     R time = 0;
     uint32_t item = 0, px = 0, py = 0, s_cur = 0, s_end = 0, seg = 0, nseg = 0, node_tests = 0, sphere_tests = 0;
     bool has_item = false, alive = false, fresh = false;
     bool queue_empty = false; // wave-uniform
 #ifdef RAYZ_BVH_PROFILE
-    unsigned long long pt[5] = {0, 0, 0, 0, 0}, pl[7] = {0, 0, 0, 0, 0, 0, 0}, px3[3] = {0, 0, 0}, pt0 = __builtin_amdgcn_s_memtime();
+    unsigned long long pt[5] = {0, 0, 0, 0, 0}, pl[7] = {0, 0, 0, 0, 0, 0, 0}, px3[3] = {0, 0, 0}, pt0 = __builtin_amdgcn_s_memtime(), fetch_ticks = 0;
 #define RAYZ_PROF_T(k) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); pt[k] += now_ - pt0; pt0 = now_; }
 #define RAYZ_PROF_L(k, n) { pl[k] += (unsigned long long)(n); pl[k + 1] += 1; }
 #else
@@ -1203,7 +1229,11 @@ template <class R> __global__ __launch_bounds__(256, RAYZ_BVH_WAVES) void trace_
                 px3[1] += __popcll(__ballot(alive && q.cur == kBvhDone && q.sp == 0u && leaf == 0u));
                 px3[2] += __popcll(__ballot(!alive));
 #endif
-                if (can_step) bvh_node_step<R>(A.sc, q, leaf, A.tmin, stack, node_tests);
+                #ifdef RAYZ_BVH_PROFILE
+                if (can_step) bvh_node_step<R>(A.sc, q, leaf, A.tmin, stack, node_tests, top, fetch_ticks);
+#else
+                if (can_step) bvh_node_step<R>(A.sc, q, leaf, A.tmin, stack, node_tests, top);
+#endif
             }
             RAYZ_PROF_T(1)
             if (__ballot(leaf != 0u) == 0ull) break; // nobody parked: every walking lane ran out of nodes
@@ -1249,6 +1279,7 @@ template <class R> __global__ __launch_bounds__(256, RAYZ_BVH_WAVES) void trace_
         for (int k = 0; k < 5; ++k) atomicAdd(&A.counters[4 + k], pt[k]);
         for (int k = 0; k < 7; ++k) atomicAdd(&A.counters[9 + k], pl[k]);
         for (int k = 0; k < 3; ++k) atomicAdd(&A.counters[16 + k], px3[k]);
+        atomicAdd(&A.counters[19], fetch_ticks);
     }
 #endif
     unsigned long long t0 = nseg, t1 = node_tests, t2 = sphere_tests;

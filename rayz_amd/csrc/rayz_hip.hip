@@ -100,6 +100,7 @@ template <class R> struct SceneBuffers {
     r4* bvh_leaf = nullptr;
     uint32_t nt_pad = 0, bvh_leaf_stride = 2, bvh_n_inner = 0;
     uint32_t n_big_leaves = 0, big_desc[4] = {0, 0, 0, 0};
+    uint32_t bvh_top = 0; // inner-node records the BVH kernel copies to LDS
     double pad_S = 0; // the origin bound S the filter radii of these buffers were padded for
     bool ready = false, bvh_ready = false;
     void release() {
@@ -418,10 +419,29 @@ template <class R> int upload_bvh_body(RayzScene* s, SceneBuffers<R>& b) {
     // one record per INNER node holding its two children's boxes (narrowed outward: never smaller than the f64
     // box) + where each child leads: an inner index, or a leaf descriptor first << 4 | type1 << 3 | type0 << 2 | count
     std::vector<r4> nodes, leaf;
-    std::vector<uint32_t> inner_index(t.nodes.size(), 0u);
+    // inner nodes are numbered breadth-first for the first kBvhTopNodes (the top levels, which the kernel keeps in LDS),
+    // the rest in pre-order
+    std::vector<uint32_t> inner_index(t.nodes.size(), 0xffffffffu), inner_order;
     uint32_t n_inner = 0;
-    for (size_t i = 0; i < t.nodes.size(); ++i)
-        if (t.nodes[i].count == 0) inner_index[i] = n_inner++;
+    {
+        const char* e = std::getenv("RAYZ_BVH_TOP"); // measurement only: number of top-of-tree records kept in LDS
+        const uint32_t top_cap = e ? (uint32_t)std::atoi(e) : (sizeof(R) == 4 ? 256u : 128u);
+        std::vector<size_t> frontier;
+        if (!t.nodes.empty() && t.nodes[0].count == 0) frontier.push_back(0);
+        for (size_t head = 0; head < frontier.size() && n_inner < top_cap; ++head) {
+            const size_t i = frontier[head];
+            inner_index[i] = n_inner++;
+            inner_order.push_back((uint32_t)i);
+            for (size_t c : {i + 1, (size_t)t.nodes[i + 1].skip})
+                if (t.nodes[c].count == 0) frontier.push_back(c);
+        }
+        b.bvh_top = n_inner;
+        for (size_t i = 0; i < t.nodes.size(); ++i)
+            if (t.nodes[i].count == 0 && inner_index[i] == 0xffffffffu) {
+                inner_index[i] = n_inner++;
+                inner_order.push_back((uint32_t)i);
+            }
+    }
     auto leaf_info = [&](const rayz_bvh::FlatNode& n) {
         uint32_t info = (n.first << 4) | n.count;
         for (uint32_t k = 0; k < n.count; ++k)
@@ -441,11 +461,10 @@ template <class R> int upload_bvh_body(RayzScene* s, SceneBuffers<R>& b) {
         child(0);
         n_inner = 1;
     } else {
-        for (size_t i = 0; i < t.nodes.size(); ++i)
-            if (t.nodes[i].count == 0) {
-                child(i + 1);                 // left child follows its parent in pre-order
-                child(t.nodes[i + 1].skip);   // right child = where the left subtree ends
-            }
+        for (uint32_t i : inner_order) { // records in index order
+            child((size_t)i + 1);             // left child follows its parent in pre-order
+            child(t.nodes[i + 1].skip);       // right child = where the left subtree ends
+        }
     }
     b.bvh_n_inner = t.nodes.empty() ? 0u : n_inner;
     for (uint32_t prim : slots) {
@@ -712,6 +731,7 @@ int render_impl(RayzScene* s, const DeviceCtx& ctx, SceneBuffers<R>& b, const Ra
     A.sc.bvh_leaf_stride = b.bvh_leaf_stride;
     A.sc.bvh_n_big_leaves = use_bvh ? b.n_big_leaves : 0u;
     for (int k = 0; k < 4; ++k) A.sc.bvh_big[k] = b.big_desc[k];
+    A.sc.bvh_top = use_bvh ? b.bvh_top : 0u;
     fill_camera<R>(cam, A.cam);
     A.partial = (r4*)s->partial;
     A.counters = s->counters;
@@ -739,7 +759,9 @@ int render_impl(RayzScene* s, const DeviceCtx& ctx, SceneBuffers<R>& b, const Ra
     int blocks_per_cu = 0;
     // the BVH kernel's LDS stack holds one entry per tree level below the root (nearer child first: the stack never
     // holds more than one entry per level); sized from THIS tree, so a shallow tree does not cap the occupancy
-    const size_t bvh_lds = use_bvh ? ((size_t)s->bvh_dev.depth + 1) * block * sizeof(uint32_t) : 0;
+    const size_t bvh_stack_bytes = use_bvh ? ((size_t)s->bvh_dev.depth + 1) * block * sizeof(uint32_t) : 0;
+    const size_t bvh_lds = bvh_stack_bytes + (use_bvh ? (size_t)b.bvh_top * 4 * sizeof(r4) : 0);
+    A.bvh_stack_words = (uint32_t)(bvh_stack_bytes / sizeof(uint32_t));
     if (use_bvh) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, trace_kernel_bvh<R>, block, bvh_lds));
     else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, trace_kernel<R, 1>, block, 0));
     if (blocks_per_cu < 1) blocks_per_cu = 1;
@@ -838,6 +860,8 @@ int scene_sync(RayzScene* s, RayzRenderStats* stats) {
                                  "no path %.1f; wave-steps per segment %.2f; shading passes %.3g, rounds %.3g\n",
                          (double)c[9] / it, (double)c[16] / it, (double)c[17] / it, (double)c[18] / it, it / (double)(c[1] ? c[1] : 1) * 1.0,
                          (double)c[15], (double)c[12]);
+            std::fprintf(stderr, "  node fetch (issue -> data): %.1f%% of the box-step phase, %.0f ticks per wave-step\n",
+                         100.0 * (double)c[19] / (double)(c[5] ? c[5] : 1), (double)c[19] / it);
         }
 #endif
         float ms = 0;
