@@ -1025,17 +1025,21 @@ __device__ __forceinline__ void bvh_node_step(const DevScene<R>& sc, BvhQuery<R>
         push = near;
         near = kBvhDone;
     }
-    if (push != kBvhDone) stack[256 * q.sp++] = push;
+    stack[256 * q.sp] = push; // unconditional: with nothing to push the word lands above the top of the stack (no branch)
+    q.sp += push != kBvhDone ? 1u : 0u;
     q.cur = near;
 }
 
 // Pop: an inner node (→ q.cur), a flagged leaf descriptor (→ parked in `leaf`), or nothing when the stack is empty.
-template <class R> __device__ __forceinline__ void bvh_pop(BvhQuery<R>& q, uint32_t& leaf, const uint32_t* stack) {
-    if (q.sp != 0u) {
-        const uint32_t e = stack[256 * --q.sp];
-        if (e & kBvhLeafFlag) leaf = e & ~kBvhLeafFlag;
-        else q.cur = e;
-    }
+// Written without branches: every lane reads a stack word (its top, or word 0), the lanes that pop keep it.
+template <class R> __device__ __forceinline__ void bvh_pop(bool want, BvhQuery<R>& q, uint32_t& leaf, const uint32_t* stack) {
+    const bool pop = want && q.sp != 0u;
+    const uint32_t spm = pop ? q.sp - 1u : 0u;
+    const uint32_t e = stack[256 * spm];
+    q.sp = pop ? spm : q.sp;
+    const bool is_leaf = (e & kBvhLeafFlag) != 0u;
+    leaf = pop && is_leaf ? e & ~kBvhLeafFlag : leaf;
+    q.cur = pop && !is_leaf ? e : q.cur;
 }
 
 // Phase L — entry k of a parked leaf: a triangle is decided here (R arithmetic only); a sphere gets the reject
@@ -1218,7 +1222,7 @@ template <class R> __global__ __launch_bounds__(256, RAYZ_BVH_WAVES) void trace_
             uint32_t leaf = 0;
             for (;;) { // phase N
                 // a lane with nothing in hand takes its next entry off the stack (an inner node, or a parked leaf)
-                if (alive && q.cur == kBvhDone && leaf == 0u) bvh_pop<R>(q, leaf, stack);
+                bvh_pop<R>(alive && q.cur == kBvhDone && leaf == 0u, q, leaf, stack);
                 const bool can_step = alive && q.cur != kBvhDone && leaf == 0u;
                 const int n_can = __popcll(__ballot(can_step));
                 if (n_can == 0) break;
