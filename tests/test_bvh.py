@@ -110,7 +110,7 @@ def test_oracle_bvh_traversal_equals_flat_list(oracle):
     testing ~37 boxes + ~5 spheres per segment instead of every sphere."""
     t = tracer.randomBouncing(96, seed=42)
     t.samples_per_px = 8
-    t.set_gpu(render_seed=3)
+    t.set_gpu(render_seed=3, traversal=capi.TRAVERSAL_LINEAR)  # (485 hittables: AUTO would walk the BVH)
     sd, cam = t.scene_desc(), t.camera_desc()
     flat, sf = oracle.render_b(sd, cam, t.params())
     t.set_gpu(traversal=capi.TRAVERSAL_BVH)

@@ -7,11 +7,11 @@ import torch
 from rayz_amd import capi, render, tracer
 
 render.init(0)
-for g in (5, 8, 11, 14, 16, 18, 20, 25, 32):
+for g in (5, 7, 8, 9, 10, 11, 12, 14, 16, 20, 32):
     row = []
     for trav in (capi.TRAVERSAL_LINEAR, capi.TRAVERSAL_BVH):
         t = tracer.randomBouncing(1920, -g, g, seed=42)
-        t.samples_per_px = 64
+        t.samples_per_px = int(os.environ.get("RAYZ_CROSSOVER_SPP", "64"))
         t.set_gpu(render_seed=1, traversal=trav)
         scene, cam, p = t.scene_desc(), t.camera_desc(), t.params()
         out = torch.empty((p.height, p.width, 3), dtype=torch.float32, device="cuda")
