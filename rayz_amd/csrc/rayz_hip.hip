@@ -748,6 +748,8 @@ int render_impl(RayzScene* s, const DeviceCtx& ctx, SceneBuffers<R>& b, const Ra
     A.shard_count = p->shard_count ? p->shard_count : 1u;
     A.shard_pixels = (uint32_t)shard_pixels64;
     A.total_items = (uint32_t)items64;
+    A.queue_grab = kQueueGrab;
+    if (const char* e = std::getenv("RAYZ_QUEUE_GRAB")) A.queue_grab = (uint32_t)std::max(1, std::atoi(e)); // measurement only
     {
         // scheduling thresholds of the BVH kernel (no effect on results); RAYZ_BVH_KEEP="active,stepping" overrides
         unsigned ka = kBvhKeepActive, ks = kBvhKeepStepping;
