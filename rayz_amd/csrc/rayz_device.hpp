@@ -353,8 +353,9 @@ template <class R> struct ScanGroup<R, 0> { // static
     typedef typename VecOf<R>::pair pr;
     static constexpr int G = group_size<R>(), H = G / 2;
     pr cx[H], cy[H], cz[H], r2[H];
-    __device__ __forceinline__ void load(const DevScene<R>& sc, int i) {
-        const RAYZ_CONSTANT pr* p = (const RAYZ_CONSTANT pr*)((const RAYZ_CONSTANT R*)sc.stat + 4 * i);
+    static __device__ __forceinline__ const RAYZ_CONSTANT R* stream(const DevScene<R>& sc) { return (const RAYZ_CONSTANT R*)sc.stat; }
+    __device__ __forceinline__ void load(const RAYZ_CONSTANT R* base, int i) {
+        const RAYZ_CONSTANT pr* p = (const RAYZ_CONSTANT pr*)(base + 4 * i);
 #pragma unroll
         for (int q = 0; q < H; ++q) cx[q] = p[q], cy[q] = p[H + q], cz[q] = p[2 * H + q], r2[q] = p[3 * H + q];
     }
@@ -384,8 +385,9 @@ template <class R> struct ScanGroup<R, 1> { // mov-Y
     typedef typename VecOf<R>::pair pr;
     static constexpr int G = group_size<R>(), H = G / 2;
     pr cx[H], cy[H], cz[H], r2[H], vy[H];
-    __device__ __forceinline__ void load(const DevScene<R>& sc, int i) {
-        const RAYZ_CONSTANT pr* p = (const RAYZ_CONSTANT pr*)((const RAYZ_CONSTANT R*)sc.movy + 5 * i);
+    static __device__ __forceinline__ const RAYZ_CONSTANT R* stream(const DevScene<R>& sc) { return (const RAYZ_CONSTANT R*)sc.movy; }
+    __device__ __forceinline__ void load(const RAYZ_CONSTANT R* base, int i) {
+        const RAYZ_CONSTANT pr* p = (const RAYZ_CONSTANT pr*)(base + 5 * i);
 #pragma unroll
         for (int q = 0; q < H; ++q)
             cx[q] = p[q], cy[q] = p[H + q], cz[q] = p[2 * H + q], r2[q] = p[3 * H + q], vy[q] = p[4 * H + q];
@@ -418,8 +420,9 @@ template <class R> struct ScanGroup<R, 2> { // mov-G
     typedef typename VecOf<R>::type r4;
     static constexpr int G = kMovGGroup;
     r4 c[G], v[G];
-    __device__ __forceinline__ void load(const DevScene<R>& sc, int i) {
-        const RAYZ_CONSTANT r4* p = (const RAYZ_CONSTANT r4*)sc.movg + 2 * i;
+    static __device__ __forceinline__ const RAYZ_CONSTANT R* stream(const DevScene<R>& sc) { return (const RAYZ_CONSTANT R*)sc.movg; }
+    __device__ __forceinline__ void load(const RAYZ_CONSTANT R* base, int i) {
+        const RAYZ_CONSTANT r4* p = (const RAYZ_CONSTANT r4*)base + 2 * i;
 #pragma unroll
         for (int k = 0; k < G; ++k) c[k] = p[2 * k], v[k] = p[2 * k + 1];
     }
@@ -517,9 +520,13 @@ template <class R, int CLS, int NR>
 __device__ __forceinline__ void scan_class(const DevScene<R>& sc, int n, ScanRay<R> (&ray)[NR], R tmin) {
     constexpr int G = ScanGroup<R, CLS>::G;
     if (n == 0) return;
+    // the stream's base as a value of its own: read out of the kernel arguments it is one lane of a 16-register block,
+    // and a spilled block comes back whole (the f64 kernel paid 20 v_readlane per iteration for this one pointer)
+    const RAYZ_CONSTANT R* base = ScanGroup<R, CLS>::stream(sc);
+    if constexpr (sizeof(R) == 8) asm volatile("" : "+s"(base));
     ScanGroup<R, CLS> a, b;
-    a.load(sc, 0);
-    b.load(sc, G);
+    a.load(base, 0);
+    b.load(base, G);
     for (int i = 0; i < n; i += 2 * G) {
         R da[NR][G], db[NR][G];
         R m = R(-1);
@@ -531,10 +538,10 @@ __device__ __forceinline__ void scan_class(const DevScene<R>& sc, int n, ScanRay
 #else
         a.touch();
         group_discs<R, CLS, NR>(a, ray, da, m, true);
-        a.load(sc, i + 2 * G);
+        a.load(base, i + 2 * G);
         __builtin_amdgcn_sched_barrier(0);
         group_discs<R, CLS, NR>(b, ray, db, m, false);
-        b.load(sc, i + 3 * G);
+        b.load(base, i + 3 * G);
         __builtin_amdgcn_sched_barrier(0);
 #endif
 #ifdef RAYZ_DEBUG_NONARROW // timing experiment only (wrong results)
@@ -553,8 +560,8 @@ __device__ __forceinline__ void scan_class(const DevScene<R>& sc, int n, ScanRay
 template <class R> struct TriGroup {
     typedef typename VecOf<R>::type r4;
     r4 a[kTriGroup], b[kTriGroup], c[kTriGroup];
-    __device__ __forceinline__ void load(const DevScene<R>& sc, int i) {
-        const RAYZ_CONSTANT r4* p = (const RAYZ_CONSTANT r4*)sc.tri + 3 * i;
+    __device__ __forceinline__ void load(const RAYZ_CONSTANT R* base, int i) {
+        const RAYZ_CONSTANT r4* p = (const RAYZ_CONSTANT r4*)base + 3 * i;
 #pragma unroll
         for (int k = 0; k < kTriGroup; ++k) a[k] = p[3 * k], b[k] = p[3 * k + 1], c[k] = p[3 * k + 2];
     }
@@ -586,15 +593,17 @@ template <class R, int NR>
 __device__ __forceinline__ void scan_triangles(const DevScene<R>& sc, ScanRay<R> (&ray)[NR], R tmin) {
     const int n = (int)sc.nt_pad;
     if (n == 0) return;
+    const RAYZ_CONSTANT R* base = (const RAYZ_CONSTANT R*)sc.tri;
+    if constexpr (sizeof(R) == 8) asm volatile("" : "+s"(base));
     TriGroup<R> a, b;
-    a.load(sc, 0);
+    a.load(base, 0);
     for (int i = 0; i < n; i += 2 * kTriGroup) {
         a.touch();
-        b.load(sc, i + kTriGroup);
+        b.load(base, i + kTriGroup);
         __builtin_amdgcn_sched_barrier(0);
         a.template test<NR>(sc, i, ray, tmin);
         b.touch();
-        a.load(sc, i + 2 * kTriGroup);
+        a.load(base, i + 2 * kTriGroup);
         __builtin_amdgcn_sched_barrier(0);
         b.template test<NR>(sc, i + kTriGroup, ray, tmin);
     }
@@ -878,7 +887,11 @@ __device__ __forceinline__ void path_refill(PathState<R>& p, const TraceArgs<R>&
 // partial[item]; resolve_kernel adds the chunk sums of a pixel in chunk order.  The summation tree is therefore
 // fixed by the chunk schedule alone — a function of (width, height, spp, chunk_spp) — not by the launch, the grid
 // size, NR or the number of GPUs.
-template <class R, int NR> __global__ __launch_bounds__(256, NR == 1 ? 4 : 3) void trace_kernel(const TraceArgs<R> A) {
+#ifndef RAYZ_FLAT_WAVES_F64
+#define RAYZ_FLAT_WAVES_F64 4
+#endif
+template <class R, int NR> constexpr int flat_waves() { return sizeof(R) == 8 ? RAYZ_FLAT_WAVES_F64 : NR == 1 ? 4 : 3; }
+template <class R, int NR> __global__ __launch_bounds__(256, (flat_waves<R, NR>())) void trace_kernel(const TraceArgs<R> A) {
     const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     PathState<R> p[NR];
 #pragma unroll
@@ -1140,7 +1153,11 @@ constexpr int kBvhKeepStepping = 16; // phase N continues while at least this ma
 #ifndef RAYZ_BVH_WAVES
 #define RAYZ_BVH_WAVES 4
 #endif
-template <class R> __global__ __launch_bounds__(256, RAYZ_BVH_WAVES) void trace_kernel_bvh(const TraceArgs<R> A) {
+#ifndef RAYZ_BVH_WAVES_F64
+#define RAYZ_BVH_WAVES_F64 3
+#endif
+template <class R> constexpr int bvh_waves() { return sizeof(R) == 8 ? RAYZ_BVH_WAVES_F64 : RAYZ_BVH_WAVES; }
+template <class R> __global__ __launch_bounds__(256, bvh_waves<R>()) void trace_kernel_bvh(const TraceArgs<R> A) {
     typedef typename VecOf<R>::type r4;
     const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     const uint32_t n_nodes = A.sc.bvh_n_nodes;
