@@ -969,8 +969,8 @@ template <class R, int NR> __global__ __launch_bounds__(256, (flat_waves<R, NR>(
 // stack (LDS) and visits the NEARER child first; the nearest hit and its tie rule do not depend on visiting
 // order, so the result is the reference's.  Per-lane state of one query:
 constexpr int kBvhStackDepth = 28;            // ≥ tree depth: median split gives ceil(log2(n / 2)) + 1 (n ≤ 2^27)
-constexpr uint32_t kBvhDone = 0xffffffffu;    // cursor: nothing left to visit
-constexpr uint32_t kBvhLeafFlag = 0x80000000u; // stack entry is a parked-leaf descriptor, not an inner index
+constexpr uint32_t kBvhDone = 0x7fffffffu;     // cursor: nothing left to visit (positive: not a leaf reference)
+constexpr uint32_t kBvhLeafFlag = 0x80000000u; // child reference / stack entry is a leaf descriptor, not an inner index
 
 template <class R> struct BvhQuery {
     V<R> inv;       // 1 / d per component
@@ -1018,11 +1018,9 @@ __device__ __forceinline__ bool bvh_box_hit(typename VecOf<R>::type lo, typename
 }
 
 // Phase N — one step of a lane that holds no parked leaf: fetch an inner node's record, slab-test both children, then
-//   * a hit leaf child is PARKED in `leaf` for phase L (a second hit leaf goes to the stack, flagged),
-//   * hit inner children: continue into the nearer, push the farther — unless a leaf was parked: then the inner child
-//     is pushed as well and the lane waits for phase L,
-//   * nothing to continue with: the caller pops.
-// The three cases exclude each other, so a step pushes at most ONE entry.  `stack` is this lane's column of the
+// take the NEARER hit child — an inner node is walked next, a leaf is PARKED in `leaf` for phase L — and push the
+// farther hit child (inner index or flagged leaf descriptor alike).  Nothing hit: the caller pops.  A step pushes at
+// most ONE entry.  `stack` is this lane's column of the
 // workgroup's LDS stack (entry s at stack[s * 256]).
 template <class R>
 __device__ __forceinline__ void bvh_node_step(const DevScene<R>& sc, BvhQuery<R>& q, uint32_t& leaf, R tmin, uint32_t* stack,
@@ -1051,28 +1049,18 @@ __device__ __forceinline__ void bvh_node_step(const DevScene<R>& sc, BvhQuery<R>
     node_tests += 2;
     R tl, tr;
     const bool hl = bvh_box_hit<R>(llo, lhi, q, tmin, tl), hr = bvh_box_hit<R>(rlo, rhi, q, tmin, tr);
-    const uint32_t lleaf = bits(lhi.w), rleaf = bits(rhi.w);
-    // inner children to continue with (kBvhDone = none), nearer first
-    uint32_t near = (hl && lleaf == 0u) ? bits(llo.w) : kBvhDone;
-    uint32_t far = (hr && rleaf == 0u) ? bits(rlo.w) : kBvhDone;
+    // each child's reference rides in its lo.w: an inner index, or kBvhLeafFlag | leaf descriptor.  Nearer child first
+    uint32_t near = hl ? bits(llo.w) : kBvhDone, far = hr ? bits(rlo.w) : kBvhDone;
     if (far != kBvhDone && (near == kBvhDone || tr < tl)) {
         const uint32_t t = near;
         near = far;
         far = t;
     }
-    // leaf children that were hit: the first is parked, a second one goes to the stack
-    const uint32_t l0 = (hl && lleaf != 0u) ? lleaf : 0u, l1 = (hr && rleaf != 0u) ? rleaf : 0u;
-    const uint32_t first = l0 != 0u ? l0 : l1, second = l0 != 0u ? l1 : 0u;
-    leaf = first;
-    uint32_t push = far;                                   // (inner, inner): the farther child
-    if (second != 0u) push = second | kBvhLeafFlag;        // (leaf, leaf)
-    if (first != 0u && near != kBvhDone) {                 // (leaf, inner): the lane stops at the leaf; the inner child waits
-        push = near;
-        near = kBvhDone;
-    }
-    stack[256 * q.sp] = push; // unconditional: with nothing to push the word lands above the top of the stack (no branch)
-    q.sp += push != kBvhDone ? 1u : 0u;
-    q.cur = near;
+    const bool park = (int32_t)near < 0; // kBvhDone is positive
+    leaf = park ? near & ~kBvhLeafFlag : 0u;
+    q.cur = park ? kBvhDone : near;
+    stack[256 * q.sp] = far; // unconditional: with nothing to push the word lands above the top of the stack (no branch)
+    q.sp += far != kBvhDone ? 1u : 0u;
 }
 
 // Pop: an inner node (→ q.cur), a flagged leaf descriptor (→ parked in `leaf`), or nothing when the stack is empty.
@@ -1291,8 +1279,13 @@ template <class R> __global__ __launch_bounds__(256, bvh_waves<R>()) void trace_
             RAYZ_PROF_T(2)
             if (__ballot((cand0 | cand1) != 0u) != 0ull) { // phase C
                 RAYZ_PROF_L(4, __popcll(__ballot((cand0 | cand1) != 0u)))
-                if (cand0 != 0u) bvh_candidate<R>(A.sc, q, cand0 - 1u, o, d, time, A.tmin);
-                if (cand1 != 0u) bvh_candidate<R>(A.sc, q, cand1 - 1u, o, d, time, A.tmin);
+                // a lane's only candidate goes into the first pass whichever entry it came from: the second pass runs
+                // only when some lane has two (the nearest hit does not depend on the order)
+                const uint32_t c0 = cand0 != 0u ? cand0 : cand1, c1 = cand0 != 0u ? cand1 : 0u;
+                if (c0 != 0u) bvh_candidate<R>(A.sc, q, c0 - 1u, o, d, time, A.tmin);
+                if (__ballot(c1 != 0u) != 0ull) {
+                    if (c1 != 0u) bvh_candidate<R>(A.sc, q, c1 - 1u, o, d, time, A.tmin);
+                }
             }
             RAYZ_PROF_T(3)
             const int n_walking = __popcll(__ballot(alive && (q.cur != kBvhDone || q.sp != 0u)));

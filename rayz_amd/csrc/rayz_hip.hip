@@ -417,7 +417,8 @@ template <class R> int upload_bvh_body(RayzScene* s, SceneBuffers<R>& b) {
     if (b.bvh_ready) return RAYZ_OK;
     b.bvh_leaf_stride = s->triangles.empty() ? 2u : 3u;
     // one record per INNER node holding its two children's boxes (narrowed outward: never smaller than the f64
-    // box) + where each child leads: an inner index, or a leaf descriptor first << 4 | type1 << 3 | type0 << 2 | count
+    // box) + in lo.w where each child leads: an inner index, or kBvhLeafFlag | leaf descriptor
+    // (first << 4 | type1 << 3 | type0 << 2 | count)
     std::vector<r4> nodes, leaf;
     // inner nodes are numbered breadth-first for the first kBvhTopNodes (the top levels, which the kernel keeps in LDS),
     // the rest in pre-order
@@ -452,9 +453,10 @@ template <class R> int upload_bvh_body(RayzScene* s, SceneBuffers<R>& b) {
         const rayz_bvh::FlatNode& n = t.nodes[c];
         const bool is_leaf = n.count != 0;
         nodes.push_back(r4{rayz_bvh::roundDown<R>(n.box.lo[0]), rayz_bvh::roundDown<R>(n.box.lo[1]),
-                           rayz_bvh::roundDown<R>(n.box.lo[2]), Bits<R>::from(is_leaf ? 0u : inner_index[c])});
+                           rayz_bvh::roundDown<R>(n.box.lo[2]),
+                           Bits<R>::from(is_leaf ? (kBvhLeafFlag | leaf_info(n)) : inner_index[c])});
         nodes.push_back(r4{rayz_bvh::roundUp<R>(n.box.hi[0]), rayz_bvh::roundUp<R>(n.box.hi[1]),
-                           rayz_bvh::roundUp<R>(n.box.hi[2]), Bits<R>::from(is_leaf ? leaf_info(n) : 0u)});
+                           rayz_bvh::roundUp<R>(n.box.hi[2]), R(0)});
     };
     if (!t.nodes.empty() && t.nodes[0].count != 0) { // the whole pool fits one leaf: a root record whose two child
         child(0);                                     // slots both name it (the repeat cannot change the result)
