@@ -686,9 +686,13 @@ template <class R> __device__ __forceinline__ V<R> refract(V<R> ud, V<R> nrm, R 
 template <class R, class G>
 __device__ __forceinline__ bool scatter_dir(uint32_t kind, uint32_t method, R param, R inv_param, G& g, V<R> d, V<R> ud, V<R> pt,
                                             V<R> nrm, bool front, V<R>& nd) {
+    // Diffuse and fuzzy-metal lanes both start from a point in the unit sphere: drawn here, ONCE for the wave's lanes of
+    // either kind (each lane consumes exactly the draws it would inside its own branch) — two rejection loops in two
+    // divergent branches cost the wave twice its slowest lane.
+    V<R> r{0, 0, 0};
+    if (kind == 0u || (kind == 1u && param > R(0))) r = random_in_unit_sphere<R>(g);
     if (kind == 0u) { // diffuse, :77-101
         V<R> target;
-        V<R> r = random_in_unit_sphere<R>(g);
         if (method == 2u) { // HEMISPHERE, :208-211
             if (!(dot3(r, nrm) > R(0))) r = neg(r);
             target = {pt.x + r.x, pt.y + r.y, pt.z + r.z};
@@ -700,14 +704,14 @@ __device__ __forceinline__ bool scatter_dir(uint32_t kind, uint32_t method, R pa
         if (ab(target.x) <= tol && ab(target.y) <= tol && ab(target.z) <= tol) target = nrm; // :85-86
         nd = {target.x - pt.x, target.y - pt.y, target.z - pt.z};
     } else if (kind == 1u) { // metallic, :108-131
-        V<R> r = unit(reflect<R>(d, nrm));
+        V<R> m = unit(reflect<R>(d, nrm));
         if (param > R(0)) {
-            const V<R> ru = unit(random_in_unit_sphere<R>(g));
+            const V<R> ru = unit(r);
             const R f = param < R(1) ? param : R(1);
-            r = {fm(ru.x, f, r.x), fm(ru.y, f, r.y), fm(ru.z, f, r.z)};
+            m = {fm(ru.x, f, m.x), fm(ru.y, f, m.y), fm(ru.z, f, m.z)};
         }
-        if (dot3(r, nrm) <= R(0)) return false; // absorbed
-        nd = r;
+        if (dot3(m, nrm) <= R(0)) return false; // absorbed
+        nd = m;
     } else { // dielectric, :137-159
         const R eta = front ? inv_param : param;
         const R cosv = -dot3(ud, nrm);
@@ -972,6 +976,25 @@ constexpr int kBvhStackDepth = 28;            // ≥ tree depth: median split gi
 constexpr uint32_t kBvhDone = 0x7fffffffu;     // cursor: nothing left to visit (positive: not a leaf reference)
 constexpr uint32_t kBvhLeafFlag = 0x80000000u; // child reference / stack entry is a leaf descriptor, not an inner index
 
+// Per-lane choices under a wave mask held in scalar registers (bit i = lane i): one vector instruction each.
+__device__ __forceinline__ uint32_t mask_select(unsigned long long m, uint32_t if_set, uint32_t if_clear) {
+    uint32_t r;
+    asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m));
+    return r;
+}
+__device__ __forceinline__ uint32_t mask_add(uint32_t x, unsigned long long m) { // x + (the lane's bit of m)
+    uint32_t r;
+    unsigned long long carry;
+    asm volatile("v_addc_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(r), "=s"(carry) : "v"(x), "s"(m));
+    return r;
+}
+__device__ __forceinline__ uint32_t mask_sub(uint32_t x, unsigned long long m) { // x − (the lane's bit of m)
+    uint32_t r;
+    unsigned long long borrow;
+    asm volatile("v_subb_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(r), "=s"(borrow) : "v"(x), "s"(m));
+    return r;
+}
+
 template <class R> struct BvhQuery {
     V<R> inv;       // 1 / d per component
     V<R> noi;       // −o · inv per component: a slab distance is ONE fma, t = fm(plane, inv, noi)
@@ -979,8 +1002,9 @@ template <class R> struct BvhQuery {
     double inv_a2;  // 1 / (d·d) in f64 for the narrow phase
     R tbest;
     int ibest;      // hittable index
-    uint32_t cur;   // inner node to visit next, or kBvhDone
-    uint32_t sp;    // stack height
+    uint32_t cur;   // what the lane holds: an inner node to visit (< kBvhDone), a parked leaf (kBvhLeafFlag | descriptor),
+                    // or kBvhDone — then the stack is empty as well and the walk is complete
+    uint32_t sp;    // index of the stack's top entry; entry 0 is a kBvhDone sentinel, so popping an empty stack ends the walk
 };
 
 template <class R> struct Slack; // relative slack of the slab test: 1 + 4 ulp
@@ -1017,13 +1041,14 @@ __device__ __forceinline__ bool bvh_box_hit(typename VecOf<R>::type lo, typename
     return fm(t1, Slack<R>::v, q.eb) >= t0;
 }
 
-// Phase N — one step of a lane that holds no parked leaf: fetch an inner node's record, slab-test both children, then
-// take the NEARER hit child — an inner node is walked next, a leaf is PARKED in `leaf` for phase L — and push the
-// farther hit child (inner index or flagged leaf descriptor alike).  Nothing hit: the caller pops.  A step pushes at
-// most ONE entry.  `stack` is this lane's column of the
-// workgroup's LDS stack (entry s at stack[s * 256]).
+// Phase N — one step of a lane that holds an inner node: fetch the node's record, slab-test both children, push the
+// farther hit child (inner index or flagged leaf descriptor alike) and take the nearer one; with nothing hit, take the
+// top of the stack instead.  Whatever the lane then holds says what it does next: an inner node → another step, a leaf →
+// parked for phase L, kBvhDone (the sentinel under the stack) → walk complete.  Branch-free: the push lands above the
+// top when there is nothing to push, the pop is a read every stepping lane makes.  `stack` is this lane's column of
+// the workgroup's LDS stack (entry s at stack[s * 256]).
 template <class R>
-__device__ __forceinline__ void bvh_node_step(const DevScene<R>& sc, BvhQuery<R>& q, uint32_t& leaf, R tmin, uint32_t* stack,
+__device__ __forceinline__ void bvh_node_step(const DevScene<R>& sc, BvhQuery<R>& q, R tmin, uint32_t* stack,
                                               uint32_t& node_tests, const typename VecOf<R>::type* top
 #ifdef RAYZ_BVH_PROFILE
                                               , unsigned long long& g_fetch_ticks
@@ -1049,30 +1074,27 @@ __device__ __forceinline__ void bvh_node_step(const DevScene<R>& sc, BvhQuery<R>
     node_tests += 2;
     R tl, tr;
     const bool hl = bvh_box_hit<R>(llo, lhi, q, tmin, tl), hr = bvh_box_hit<R>(rlo, rhi, q, tmin, tr);
-    // each child's reference rides in its lo.w: an inner index, or kBvhLeafFlag | leaf descriptor.  Nearer child first
-    uint32_t near = hl ? bits(llo.w) : kBvhDone, far = hr ? bits(rlo.w) : kBvhDone;
-    if (far != kBvhDone && (near == kBvhDone || tr < tl)) {
-        const uint32_t t = near;
-        near = far;
-        far = t;
-    }
-    const bool park = (int32_t)near < 0; // kBvhDone is positive
-    leaf = park ? near & ~kBvhLeafFlag : 0u;
-    q.cur = park ? kBvhDone : near;
-    stack[256 * q.sp] = far; // unconditional: with nothing to push the word lands above the top of the stack (no branch)
-    q.sp += far != kBvhDone ? 1u : 0u;
+    // each child's reference rides in its lo.w: an inner index, or kBvhLeafFlag | leaf descriptor.  Nearer child first;
+    // the decisions are kept as lane masks (which child was hit is all that push and pop depend on)
+    // Which child was hit decides everything below, so the decisions live as WAVE MASKS in scalar registers (the boolean
+    // algebra runs on the scalar unit, which has slack; the vector unit, which has none, spends one v_cndmask per choice):
+    const unsigned long long ml = __ballot(hl), mr = __ballot(hr), mlt = __ballot(tr < tl);
+    const unsigned long long swap = mr & (~ml | mlt), both = ml & mr, none = ~(ml | mr);
+    // (a child that was not hit may ride along as `near` or `far`: `none` and `both` decide what is used)
+    const uint32_t l = bits(llo.w), r = bits(rlo.w);
+    const uint32_t near = mask_select(swap, r, l), far = mask_select(swap, l, r);
+    stack[256 * (q.sp + 1u)] = far; // lands above the top unless both were hit
+    const uint32_t sp = mask_add(q.sp, both);
+    const uint32_t e = stack[256 * sp]; // read by every stepping lane, used when nothing was hit (never the word just written)
+    q.cur = mask_select(none, e, near);
+    q.sp = mask_sub(sp, none); // popping the sentinel leaves sp at −1: the lane holds kBvhDone and touches the stack no
+                               // more until bvh_begin
 }
 
-// Pop: an inner node (→ q.cur), a flagged leaf descriptor (→ parked in `leaf`), or nothing when the stack is empty.
-// Written without branches: every lane reads a stack word (its top, or word 0), the lanes that pop keep it.
-template <class R> __device__ __forceinline__ void bvh_pop(bool want, BvhQuery<R>& q, uint32_t& leaf, const uint32_t* stack) {
-    const bool pop = want && q.sp != 0u;
-    const uint32_t spm = pop ? q.sp - 1u : 0u;
-    const uint32_t e = stack[256 * spm];
-    q.sp = pop ? spm : q.sp;
-    const bool is_leaf = (e & kBvhLeafFlag) != 0u;
-    leaf = pop && is_leaf ? e & ~kBvhLeafFlag : leaf;
-    q.cur = pop && !is_leaf ? e : q.cur;
+// The next entry of a lane that is done with its parked leaf.
+template <class R> __device__ __forceinline__ void bvh_pop(BvhQuery<R>& q, const uint32_t* stack) {
+    q.cur = stack[256 * q.sp];
+    q.sp -= 1u;
 }
 
 // Phase L — entry k of a parked leaf: a triangle is decided here (R arithmetic only); a sphere gets the reject
@@ -1168,6 +1190,7 @@ template <class R> __global__ __launch_bounds__(256, bvh_waves<R>()) void trace_
     // behind the stacks (A.bvh_stack_words u32s, a multiple of 64 B): the top of the tree, copied once per workgroup
     r4* top = (r4*)(lds_stack + A.bvh_stack_words);
     for (uint32_t k = threadIdx.x; k < 4u * A.sc.bvh_top; k += 256u) top[k] = A.sc.bvh_nodes[k];
+    stack[0] = kBvhDone; // the sentinel under every lane's stack
     __syncthreads();
     R time = 0;
     uint32_t item = 0, px = 0, py = 0, s_cur = 0, s_end = 0, seg = 0, nseg = 0, node_tests = 0, sphere_tests = 0;
@@ -1247,34 +1270,32 @@ template <class R> __global__ __launch_bounds__(256, bvh_waves<R>()) void trace_
         // ---- rounds of (N) box steps, (L) leaf tests, (C) candidate roots ----
         const int n_alive = __popcll(__ballot(alive));
         for (;;) {
-            uint32_t leaf = 0;
-            for (;;) { // phase N
-                // a lane with nothing in hand takes its next entry off the stack (an inner node, or a parked leaf)
-                bvh_pop<R>(alive && q.cur == kBvhDone && leaf == 0u, q, leaf, stack);
-                const bool can_step = alive && q.cur != kBvhDone && leaf == 0u;
+            for (;;) { // phase N: lanes holding an inner node step; lanes holding a leaf wait
+                const bool can_step = q.cur < kBvhDone;
                 const int n_can = __popcll(__ballot(can_step));
                 if (n_can == 0) break;
-                if (n_can < keep_stepping && __ballot(leaf != 0u) != 0ull) break;
+                if (n_can < keep_stepping && __ballot((int32_t)q.cur < 0) != 0ull) break;
                 RAYZ_PROF_L(0, n_can)
 #ifdef RAYZ_BVH_PROFILE
-                px3[0] += __popcll(__ballot(alive && leaf != 0u));
-                px3[1] += __popcll(__ballot(alive && q.cur == kBvhDone && q.sp == 0u && leaf == 0u));
+                px3[0] += __popcll(__ballot((int32_t)q.cur < 0));
+                px3[1] += __popcll(__ballot(alive && q.cur == kBvhDone));
                 px3[2] += __popcll(__ballot(!alive));
-#endif
-                #ifdef RAYZ_BVH_PROFILE
-                if (can_step) bvh_node_step<R>(A.sc, q, leaf, A.tmin, stack, node_tests, top, fetch_ticks);
+                if (can_step) bvh_node_step<R>(A.sc, q, A.tmin, stack, node_tests, top, fetch_ticks);
 #else
-                if (can_step) bvh_node_step<R>(A.sc, q, leaf, A.tmin, stack, node_tests, top);
+                if (can_step) bvh_node_step<R>(A.sc, q, A.tmin, stack, node_tests, top);
 #endif
             }
             RAYZ_PROF_T(1)
-            if (__ballot(leaf != 0u) == 0ull) break; // nobody parked: every walking lane ran out of nodes
-            RAYZ_PROF_L(2, __popcll(__ballot(leaf != 0u)))
+            const bool parked = (int32_t)q.cur < 0;
+            if (__ballot(parked) == 0ull) break; // nobody parked: every walking lane ran out of nodes
+            RAYZ_PROF_L(2, __popcll(__ballot(parked)))
             uint32_t cand0 = 0, cand1 = 0;
-            if (leaf != 0u) { // phase L
+            if (parked) { // phase L
+                const uint32_t leaf = q.cur & ~kBvhLeafFlag;
                 sphere_tests += leaf & 3u;
                 cand0 = bvh_leaf_entry<R>(A.sc, q, leaf, 0u, o, d, ud, time, A.tmin);
                 if ((leaf & 3u) > 1u) cand1 = bvh_leaf_entry<R>(A.sc, q, leaf, 1u, o, d, ud, time, A.tmin);
+                bvh_pop<R>(q, stack);
             }
             RAYZ_PROF_T(2)
             if (__ballot((cand0 | cand1) != 0u) != 0ull) { // phase C
@@ -1288,7 +1309,7 @@ template <class R> __global__ __launch_bounds__(256, bvh_waves<R>()) void trace_
                 }
             }
             RAYZ_PROF_T(3)
-            const int n_walking = __popcll(__ballot(alive && (q.cur != kBvhDone || q.sp != 0u)));
+            const int n_walking = __popcll(__ballot(q.cur != kBvhDone));
             if (n_walking == 0) break;
             if (n_walking < keep_active && n_walking < n_alive) break; // finished lanes wait: go shade / refill them
         }
@@ -1296,9 +1317,9 @@ template <class R> __global__ __launch_bounds__(256, bvh_waves<R>()) void trace_
         // ---- shade lanes whose query is complete ----
         RAYZ_PROF_T(1)
 #ifdef RAYZ_BVH_PROFILE
-        pl[6] += __ballot(alive && q.cur == kBvhDone && q.sp == 0u) != 0ull ? 1ull : 0ull; // shade passes
+        pl[6] += __ballot(alive && q.cur == kBvhDone) != 0ull ? 1ull : 0ull; // shade passes
 #endif
-        if (alive && q.cur == kBvhDone && q.sp == 0u) {
+        if (alive && q.cur == kBvhDone) {
             nseg++;
             seg++;
             bool cont = shade<R>(A.sc, g, o, d, ud, time, q.tbest, q.ibest, thr, acc);

@@ -763,7 +763,7 @@ int render_impl(RayzScene* s, const DeviceCtx& ctx, SceneBuffers<R>& b, const Ra
     int blocks_per_cu = 0;
     // the BVH kernel's LDS stack holds one entry per tree level below the root (nearer child first: the stack never
     // holds more than one entry per level); sized from THIS tree, so a shallow tree does not cap the occupancy
-    const size_t bvh_stack_bytes = use_bvh ? ((size_t)s->bvh_dev.depth + 1) * block * sizeof(uint32_t) : 0;
+    const size_t bvh_stack_bytes = use_bvh ? ((size_t)s->bvh_dev.depth + 2) * block * sizeof(uint32_t) : 0;
     const size_t bvh_lds = bvh_stack_bytes + (use_bvh ? (size_t)b.bvh_top * 4 * sizeof(r4) : 0);
     A.bvh_stack_words = (uint32_t)(bvh_stack_bytes / sizeof(uint32_t));
     if (use_bvh) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, trace_kernel_bvh<R>, block, bvh_lds));
