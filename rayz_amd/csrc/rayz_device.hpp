@@ -106,7 +106,7 @@ template <class R> struct TraceArgs {
     uint32_t tile_rows, shard_index, shard_count, shard_pixels;
     uint32_t total_items;
     uint32_t bvh_keep;       // BVH kernel: keep_active | keep_stepping << 8 (see trace_kernel_bvh)
-    uint32_t bvh_stack_words; // BVH kernel: u32s of LDS taken by the per-lane stacks (the tree's top follows)
+    uint32_t bvh_top_words;   // BVH kernel: u32s of LDS taken by the copy of the tree's top (the per-lane stacks follow)
     uint32_t queue_grab;     // work items a wave reserves per atomic on the queue head (kQueueGrab; scheduling only)
 };
 
@@ -995,6 +995,28 @@ __device__ __forceinline__ uint32_t mask_sub(uint32_t x, unsigned long long m) {
     return r;
 }
 
+// max / min of a computed value x and a bound the caller knows is not NaN: the bare instruction.
+__device__ __forceinline__ float max_bound(float x, float bound) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(bound));
+    return r;
+}
+__device__ __forceinline__ float min_bound(float x, float bound) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(bound));
+    return r;
+}
+__device__ __forceinline__ double max_bound(double x, double bound) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(bound));
+    return r;
+}
+__device__ __forceinline__ double min_bound(double x, double bound) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(bound));
+    return r;
+}
+
 template <class R> struct BvhQuery {
     V<R> inv;       // 1 / d per component
     V<R> noi;       // −o · inv per component: a slab distance is ONE fma, t = fm(plane, inv, noi)
@@ -1036,8 +1058,10 @@ __device__ __forceinline__ bool bvh_box_hit(typename VecOf<R>::type lo, typename
     const R ax = fm(lo.x, q.inv.x, q.noi.x), bx = fm(hi.x, q.inv.x, q.noi.x);
     const R ay = fm(lo.y, q.inv.y, q.noi.y), by = fm(hi.y, q.inv.y, q.noi.y);
     const R az = fm(lo.z, q.inv.z, q.noi.z), bz = fm(hi.z, q.inv.z, q.noi.z);
-    t0 = mx(mx(mn(ax, bx), mn(ay, by)), mx(mn(az, bz), tmin));
-    const R t1 = mn(mn(mx(ax, bx), mx(ay, by)), mn(mx(az, bz), q.tbest));
+    // (tmin and tbest are never NaN: max_bound / min_bound spare the canonicalising copy fmax / fmin would put in front of
+    // every use — two vector instructions per step)
+    t0 = mx(mx(mn(ax, bx), mn(ay, by)), max_bound(mn(az, bz), tmin));
+    const R t1 = mn(mn(mx(ax, bx), mx(ay, by)), min_bound(mx(az, bz), q.tbest));
     return fm(t1, Slack<R>::v, q.eb) >= t0;
 }
 
@@ -1049,7 +1073,7 @@ __device__ __forceinline__ bool bvh_box_hit(typename VecOf<R>::type lo, typename
 // the workgroup's LDS stack (entry s at stack[s * 256]).
 template <class R>
 __device__ __forceinline__ void bvh_node_step(const DevScene<R>& sc, BvhQuery<R>& q, R tmin, uint32_t* stack,
-                                              uint32_t& node_tests, const typename VecOf<R>::type* top
+                                              const typename VecOf<R>::type* top
 #ifdef RAYZ_BVH_PROFILE
                                               , unsigned long long& g_fetch_ticks
 #endif
@@ -1059,7 +1083,35 @@ __device__ __forceinline__ void bvh_node_step(const DevScene<R>& sc, BvhQuery<R>
 #ifdef RAYZ_BVH_PROFILE
     const unsigned long long tl0 = __builtin_amdgcn_s_memtime();
 #endif
-    if (q.cur < sc.bvh_top) { // top of the tree: from the workgroup's LDS copy
+    if constexpr (sizeof(R) == 4) {
+        // Both homes of a node — the LDS copy of the tree's top, global memory for the rest — are read from the SAME
+        // 32-bit offset (index << 6): the lanes of either kind take turns under exec, into the same registers.  Two
+        // vector instructions (a compare, a shift) instead of the nine a flat-address select costs.
+        (void)top;
+        const unsigned long long in_top = __ballot(q.cur < sc.bvh_top);
+        const uint32_t off = q.cur << 6; // (the host keeps the node count below 2^26)
+        unsigned long long saved;
+        asm volatile("s_mov_b64 %[sv], exec\n\t"
+                     "s_and_b64 exec, %[sv], %[mt]\n\t" // (SCC = some lane: an empty turn is skipped — the memory
+                     "s_cbranch_scc0 1f\n\t"            //  pipes would still spend their cycles on it)
+                     "ds_read_b128 %[n0], %[off]\n\t"
+                     "ds_read_b128 %[n1], %[off] offset:16\n\t"
+                     "ds_read_b128 %[n2], %[off] offset:32\n\t"
+                     "ds_read_b128 %[n3], %[off] offset:48\n"
+                     "1:\n\t"
+                     "s_andn2_b64 exec, %[sv], %[mt]\n\t"
+                     "s_cbranch_scc0 2f\n\t"
+                     "global_load_dwordx4 %[n0], %[off], %[base]\n\t"
+                     "global_load_dwordx4 %[n1], %[off], %[base] offset:16\n\t"
+                     "global_load_dwordx4 %[n2], %[off], %[base] offset:32\n\t"
+                     "global_load_dwordx4 %[n3], %[off], %[base] offset:48\n"
+                     "2:\n\t"
+                     "s_mov_b64 exec, %[sv]\n\t"
+                     "s_waitcnt vmcnt(0) lgkmcnt(0)"
+                     : [n0] "=&v"(llo), [n1] "=&v"(lhi), [n2] "=&v"(rlo), [n3] "=&v"(rhi), [sv] "=&s"(saved)
+                     : [off] "v"(off), [mt] "s"(in_top), [base] "s"(sc.bvh_nodes)
+                     : "memory", "scc");
+    } else if (q.cur < sc.bvh_top) { // top of the tree: from the workgroup's LDS copy
         const r4* p = top + 4 * (size_t)q.cur;
         llo = p[0], lhi = p[1], rlo = p[2], rhi = p[3];
     } else {
@@ -1068,10 +1120,8 @@ __device__ __forceinline__ void bvh_node_step(const DevScene<R>& sc, BvhQuery<R>
     }
 #ifdef RAYZ_BVH_PROFILE // time from issuing the node fetch to having it (the wave's own view), accumulated in g_prof_fetch
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    node_tests += 0u;
     g_fetch_ticks += __builtin_amdgcn_s_memtime() - tl0;
 #endif
-    node_tests += 2;
     R tl, tr;
     const bool hl = bvh_box_hit<R>(llo, lhi, q, tmin, tl), hr = bvh_box_hit<R>(rlo, rhi, q, tmin, tr);
     // each child's reference rides in its lo.w: an inner index, or kBvhLeafFlag | leaf descriptor.  Nearer child first;
@@ -1183,17 +1233,18 @@ template <class R> __global__ __launch_bounds__(256, bvh_waves<R>()) void trace_
     q.ibest = -1;
     q.cur = kBvhDone;
     q.sp = 0;
-    // per-lane traversal stack in LDS, sized by the launch from the tree's depth (dynamic shared memory): entry s of this
-    // lane at stack[256 * s] — conflict-free for any mix of s
-    extern __shared__ uint32_t lds_stack[];
-    uint32_t* stack = lds_stack + threadIdx.x;
-    // behind the stacks (A.bvh_stack_words u32s, a multiple of 64 B): the top of the tree, copied once per workgroup
-    r4* top = (r4*)(lds_stack + A.bvh_stack_words);
+    // dynamic shared memory, from LDS address 0 (the kernel has no static LDS): the top of the tree, copied once per
+    // workgroup (A.bvh_top_words u32s; a node's LDS address is its index << 6 for f32), then the per-lane traversal stacks,
+    // sized by the launch from the tree's depth: entry s of this lane at stack[256 * s] — conflict-free for any mix of s
+    extern __shared__ uint32_t lds_words[];
+    r4* top = (r4*)lds_words;
+    uint32_t* stack = lds_words + A.bvh_top_words + threadIdx.x;
     for (uint32_t k = threadIdx.x; k < 4u * A.sc.bvh_top; k += 256u) top[k] = A.sc.bvh_nodes[k];
     stack[0] = kBvhDone; // the sentinel under every lane's stack
     __syncthreads();
     R time = 0;
-    uint32_t item = 0, px = 0, py = 0, s_cur = 0, s_end = 0, seg = 0, nseg = 0, node_tests = 0, sphere_tests = 0;
+    uint32_t item = 0, px = 0, py = 0, s_cur = 0, s_end = 0, seg = 0, nseg = 0, sphere_tests = 0;
+    uint32_t node_tests = 0; // counted per WAVE (two per stepping lane, off the step's own lane count): scalar arithmetic
     bool has_item = false, alive = false, fresh = false;
     WaveQueue wq; // wave-uniform
 #ifdef RAYZ_BVH_PROFILE
@@ -1227,8 +1278,8 @@ template <class R> __global__ __launch_bounds__(256, bvh_waves<R>()) void trace_
                 acc = {R(0), R(0), R(0)};
             }
             // the per-lane u32 statistics would wrap after ≈30 minutes inside one launch: spill them when half full
-            if (popping && __ballot(node_tests > RAYZ_STAT_SPILL) != 0ull) {
-                atomicAdd(&A.counters[2], (unsigned long long)node_tests);
+            if (popping && node_tests > RAYZ_STAT_SPILL) {
+                if (lane == 0) atomicAdd(&A.counters[2], (unsigned long long)node_tests);
                 atomicAdd(&A.counters[3], (unsigned long long)sphere_tests);
                 atomicAdd(&A.counters[1], (unsigned long long)nseg);
                 node_tests = sphere_tests = nseg = 0;
@@ -1280,10 +1331,11 @@ template <class R> __global__ __launch_bounds__(256, bvh_waves<R>()) void trace_
                 px3[0] += __popcll(__ballot((int32_t)q.cur < 0));
                 px3[1] += __popcll(__ballot(alive && q.cur == kBvhDone));
                 px3[2] += __popcll(__ballot(!alive));
-                if (can_step) bvh_node_step<R>(A.sc, q, A.tmin, stack, node_tests, top, fetch_ticks);
+                if (can_step) bvh_node_step<R>(A.sc, q, A.tmin, stack, top, fetch_ticks);
 #else
-                if (can_step) bvh_node_step<R>(A.sc, q, A.tmin, stack, node_tests, top);
+                if (can_step) bvh_node_step<R>(A.sc, q, A.tmin, stack, top);
 #endif
+                node_tests += 2u * (uint32_t)n_can;
             }
             RAYZ_PROF_T(1)
             const bool parked = (int32_t)q.cur < 0;
@@ -1344,7 +1396,6 @@ template <class R> __global__ __launch_bounds__(256, bvh_waves<R>()) void trace_
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         t0 += __shfl_xor(t0, off);
-        t1 += __shfl_xor(t1, off);
         t2 += __shfl_xor(t2, off);
     }
     if (lane == 0) {

@@ -468,6 +468,8 @@ template <class R> int upload_bvh_body(RayzScene* s, SceneBuffers<R>& b) {
             child(t.nodes[i + 1].skip);       // right child = where the left subtree ends
         }
     }
+    if (n_inner >= (1u << 26)) // the f32 walk addresses a record by a 32-bit byte offset (index << 6)
+        return fail(RAYZ_ERR_BAD_ARG, "BVH of %u inner nodes exceeds the device layout (2^26)", n_inner);
     b.bvh_n_inner = t.nodes.empty() ? 0u : n_inner;
     for (uint32_t prim : slots) {
         if (prim < ns) {
@@ -764,8 +766,9 @@ int render_impl(RayzScene* s, const DeviceCtx& ctx, SceneBuffers<R>& b, const Ra
     // the BVH kernel's LDS stack holds one entry per tree level below the root (nearer child first: the stack never
     // holds more than one entry per level); sized from THIS tree, so a shallow tree does not cap the occupancy
     const size_t bvh_stack_bytes = use_bvh ? ((size_t)s->bvh_dev.depth + 2) * block * sizeof(uint32_t) : 0;
-    const size_t bvh_lds = bvh_stack_bytes + (use_bvh ? (size_t)b.bvh_top * 4 * sizeof(r4) : 0);
-    A.bvh_stack_words = (uint32_t)(bvh_stack_bytes / sizeof(uint32_t));
+    const size_t bvh_top_bytes = use_bvh ? (size_t)b.bvh_top * 4 * sizeof(r4) : 0; // the tree's top: first in LDS
+    const size_t bvh_lds = bvh_top_bytes + bvh_stack_bytes;
+    A.bvh_top_words = (uint32_t)(bvh_top_bytes / sizeof(uint32_t));
     if (use_bvh) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, trace_kernel_bvh<R>, block, bvh_lds));
     else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, trace_kernel<R, 1>, block, 0));
     if (blocks_per_cu < 1) blocks_per_cu = 1;
