@@ -1111,12 +1111,45 @@ __device__ __forceinline__ void bvh_node_step(const DevScene<R>& sc, BvhQuery<R>
                      : [n0] "=&v"(llo), [n1] "=&v"(lhi), [n2] "=&v"(rlo), [n3] "=&v"(rhi), [sv] "=&s"(saved)
                      : [off] "v"(off), [mt] "s"(in_top), [base] "s"(sc.bvh_nodes)
                      : "memory", "scc");
-    } else if (q.cur < sc.bvh_top) { // top of the tree: from the workgroup's LDS copy
-        const r4* p = top + 4 * (size_t)q.cur;
-        llo = p[0], lhi = p[1], rlo = p[2], rhi = p[3];
-    } else {
-        const r4* p = sc.bvh_nodes + 4 * (size_t)q.cur;
-        llo = p[0], lhi = p[1], rlo = p[2], rhi = p[3];
+    } else { // f64: the same two turns, a record is 128 bytes (eight 16-byte halves)
+        (void)top;
+        const unsigned long long in_top = __ballot(q.cur < sc.bvh_top);
+        const uint32_t off = q.cur << 7; // (node count below 2^25 for f64: checked by the host)
+        unsigned long long saved;
+        d2 h0, h1, h2, h3, h4, h5, h6, h7;
+        asm volatile("s_mov_b64 %[sv], exec\n\t"
+                     "s_and_b64 exec, %[sv], %[mt]\n\t"
+                     "s_cbranch_scc0 1f\n\t"
+                     "ds_read_b128 %[h0], %[off]\n\t"
+                     "ds_read_b128 %[h1], %[off] offset:16\n\t"
+                     "ds_read_b128 %[h2], %[off] offset:32\n\t"
+                     "ds_read_b128 %[h3], %[off] offset:48\n\t"
+                     "ds_read_b128 %[h4], %[off] offset:64\n\t"
+                     "ds_read_b128 %[h5], %[off] offset:80\n\t"
+                     "ds_read_b128 %[h6], %[off] offset:96\n\t"
+                     "ds_read_b128 %[h7], %[off] offset:112\n"
+                     "1:\n\t"
+                     "s_andn2_b64 exec, %[sv], %[mt]\n\t"
+                     "s_cbranch_scc0 2f\n\t"
+                     "global_load_dwordx4 %[h0], %[off], %[base]\n\t"
+                     "global_load_dwordx4 %[h1], %[off], %[base] offset:16\n\t"
+                     "global_load_dwordx4 %[h2], %[off], %[base] offset:32\n\t"
+                     "global_load_dwordx4 %[h3], %[off], %[base] offset:48\n\t"
+                     "global_load_dwordx4 %[h4], %[off], %[base] offset:64\n\t"
+                     "global_load_dwordx4 %[h5], %[off], %[base] offset:80\n\t"
+                     "global_load_dwordx4 %[h6], %[off], %[base] offset:96\n\t"
+                     "global_load_dwordx4 %[h7], %[off], %[base] offset:112\n"
+                     "2:\n\t"
+                     "s_mov_b64 exec, %[sv]\n\t"
+                     "s_waitcnt vmcnt(0) lgkmcnt(0)"
+                     : [h0] "=&v"(h0), [h1] "=&v"(h1), [h2] "=&v"(h2), [h3] "=&v"(h3), [h4] "=&v"(h4), [h5] "=&v"(h5),
+                       [h6] "=&v"(h6), [h7] "=&v"(h7), [sv] "=&s"(saved)
+                     : [off] "v"(off), [mt] "s"(in_top), [base] "s"(sc.bvh_nodes)
+                     : "memory", "scc");
+        llo = r4{(R)h0.x, (R)h0.y, (R)h1.x, (R)h1.y};
+        lhi = r4{(R)h2.x, (R)h2.y, (R)h3.x, (R)h3.y};
+        rlo = r4{(R)h4.x, (R)h4.y, (R)h5.x, (R)h5.y};
+        rhi = r4{(R)h6.x, (R)h6.y, (R)h7.x, (R)h7.y};
     }
 #ifdef RAYZ_BVH_PROFILE // time from issuing the node fetch to having it (the wave's own view), accumulated in g_prof_fetch
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");

@@ -468,8 +468,8 @@ template <class R> int upload_bvh_body(RayzScene* s, SceneBuffers<R>& b) {
             child(t.nodes[i + 1].skip);       // right child = where the left subtree ends
         }
     }
-    if (n_inner >= (1u << 26)) // the f32 walk addresses a record by a 32-bit byte offset (index << 6)
-        return fail(RAYZ_ERR_BAD_ARG, "BVH of %u inner nodes exceeds the device layout (2^26)", n_inner);
+    if (n_inner >= (1u << 25)) // the walk addresses a record by a 32-bit byte offset (index << 6 for f32, << 7 for f64)
+        return fail(RAYZ_ERR_BAD_ARG, "BVH of %u inner nodes exceeds the device layout (2^25)", n_inner);
     b.bvh_n_inner = t.nodes.empty() ? 0u : n_inner;
     for (uint32_t prim : slots) {
         if (prim < ns) {
