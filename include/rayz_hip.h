@@ -63,7 +63,7 @@ typedef enum RayzTraversal {
     RAYZ_TRAVERSAL_BVH = 1,    /* the reference's accelerator, src/hit.zig:101-217 */
     RAYZ_TRAVERSAL_AUTO = 2    /* flat list up to RAYZ_AUTO_BVH_MIN hittables, BVH above (same image either way) */
 } RayzTraversal;
-#define RAYZ_AUTO_BVH_MIN 352u /* measured crossover on MI355X: tools/crossover.py, profiles/r02/crossover.log */
+#define RAYZ_AUTO_BVH_MIN 160u /* measured crossover on MI355X: tools/crossover.py, profiles/r02/crossover.log */
 
 /* One entry of `MemPool.textures` (src/ecs.zig:26): SolidTexture src/material.zig:19-25 or
  * CheckerTexture src/material.zig:27-39.  `even`/`odd` are TextureHandle.idx values. */

@@ -71,7 +71,7 @@ pub const RayzRenderParams = extern struct {
     seed: u64,
     tmin: f64,
     precision: u32 = 0, // 0 f32 (tmin 1e-3), 1 f64 (the reference's 1e-10)
-    traversal: u32 = 2, // 0 flat list, 1 BVH, 2 auto (flat list up to 352 hittables, BVH above)
+    traversal: u32 = 2, // 0 flat list, 1 BVH, 2 auto (flat list up to 160 hittables, BVH above)
     chunk_spp: u32 = 0,
     tile_rows: u32 = 0,
     shard_index: u32 = 0,

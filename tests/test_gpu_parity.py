@@ -253,9 +253,9 @@ def test_tonemap_u8_matches_write_ppm(gpu, oracle):
 
 def test_traversal_auto_picks_by_scene_size(gpu, oracle):
     """RAYZ_TRAVERSAL_AUTO (the host mirror's default; the reference always walks its BVH): flat list up to
-    RAYZ_AUTO_BVH_MIN = 352 hittables, BVH above; the oracle resolves AUTO the same way and images match bit for bit."""
-    small, big = tracer.randomBouncing(64, -8, 8, seed=42), tracer.randomBouncing(64, seed=42)
-    assert small.info().n_spheres <= 352 < big.info().n_spheres  # 256 spheres / the reference's own scene (485)
+    RAYZ_AUTO_BVH_MIN = 160 hittables, BVH above; the oracle resolves AUTO the same way and images match bit for bit."""
+    small, big = tracer.randomBouncing(64, -5, 5, seed=42), tracer.randomBouncing(64, seed=42)
+    assert small.info().n_spheres <= 160 < big.info().n_spheres  # 100 spheres / the reference's own scene (485)
     for t, bvh in ((small, False), (big, True)):
         t.samples_per_px = 4
         t.set_gpu(render_seed=3)

@@ -7,7 +7,7 @@ import torch
 from rayz_amd import capi, render, tracer
 
 render.init(0)
-for g in (5, 7, 8, 9, 10, 11, 12, 14, 16, 20, 32):
+for g in (3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 16, 20, 32):
     row = []
     for trav in (capi.TRAVERSAL_LINEAR, capi.TRAVERSAL_BVH):
         t = tracer.randomBouncing(1920, -g, g, seed=42)
