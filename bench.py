@@ -363,7 +363,8 @@ def run(args, json_fd):
             flops = (st_last.node_tests * FLOP_PER_BOX_TEST + st_last.sphere_tests * FLOP_PER_TEST_MOVING)
             executed_flops = flops
             kernel = "trace_kernel_bvh<%s>" % ("double" if args.precision == "f64" else "float")
-            note = ("per-lane tree walk: divergence- and latency-bound, priced against the same FP32 vector peak; "
+            note = ("per-lane tree walk: vector-ALU issue-bound at ~60 % lane use (SQ_ACTIVE_INST_VALU = 90 % of the SIMD "
+                    "cycles, profiles/r02/pmc_summary.json), priced against the same FP32 vector peak; "
                     f"algorithmic flops = {FLOP_PER_BOX_TEST} x box tests + 24 x leaf sphere tests")
         peak = PEAK_VALU_F64_TFLOPS if args.precision == "f64" else PEAK_VALU_F32_TFLOPS
         reference_achieved = flops / (kernel_ms_avg * 1e-3) / 1e12   # SURVEY 8d accounting
@@ -384,7 +385,7 @@ def run(args, json_fd):
             except Exception:
                 traffic = None
         out = {
-            "metric": "Msamples/sec, 10k-sphere 1920x1080x1024spp (flat hit list)",
+            "metric": "Msamples/sec, 10k-sphere 1920x1080x1024spp (%s)" % ("flat hit list" if args.traversal == "linear" else "BVH traversal"),
             "value": samples_per_step * args.steps / elapsed / 1e6,
             "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
