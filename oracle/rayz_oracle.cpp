@@ -1030,7 +1030,14 @@ template <class R> struct SlabRay {
 };
 template <class R> static SlabRay<R> slabRay(V<R> o, V<R> d) {
     SlabRay<R> s;
-    s.inv = {R(1) / d.x, R(1) / d.y, R(1) / d.z};
+    // reciprocals held to ±K (2^64 / 2^512): a zero direction component must not reach the test as ±inf — one plane of a
+    // box that straddles 0 then gives −inf, the other NaN, and max(−inf, NaN) = −inf culls a box the ray lies inside
+    const R K = sizeof(R) == 4 ? (R)0x1p64 : (R)0x1p512;
+    auto inv = [K](R dk) {
+        const R r = R(1) / dk;
+        return r > K ? K : (r < -K ? -K : r);
+    };
+    s.inv = {inv(d.x), inv(d.y), inv(d.z)};
     s.noi = {-(o.x * s.inv.x), -(o.y * s.inv.y), -(o.z * s.inv.z)};
     auto fa = [](R v) { return std::fabs(v) <= (R)3.0e38 ? std::fabs(v) : R(0); };
     const R u4 = R(4) * (std::numeric_limits<R>::epsilon() / R(2));

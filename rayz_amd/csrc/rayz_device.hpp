@@ -1034,8 +1034,22 @@ template <> struct Slack<float> { static constexpr float v = 1.0f + 4.0f * 1.192
 template <> struct Slack<double> { static constexpr double v = 1.0 + 4.0 * 2.220446049250313e-16, u4 = 4.0 * 1.1102230246251565e-16; };
 
 template <class R> __device__ __forceinline__ R finite_abs(R v) { return ab(v) <= (R)3.0e38 ? ab(v) : R(0); } // 0 for ±inf / NaN
+// 1 / d_k, held to ±K (2^64 for f32, 2^512 for f64).  A direction component of 0 (or so small that its reciprocal
+// overflows) must not reach the slab test as ±inf: fm(plane, ±inf, −o·(±inf)) is −inf for one plane of a box that
+// straddles 0 and NaN for the other, and max(−inf, NaN) = −inf then culls a box the ray lies inside.  (Such
+// directions are not exotic: a diffuse scatter at |p_k| = 50 returns exactly 0 in one component about once in 10^5
+// bounces, when the offset is absorbed by the rounding of p_k + r_k.)  With the clamp the ray is treated as one whose
+// component is 1 / K: finite distances of the right sign, and the absolute slack eb — which then carries K·|o_k| —
+// covers their rounding.
+template <class R> struct InvCap;
+template <> struct InvCap<float> { static constexpr float v = 0x1p64f; };
+template <> struct InvCap<double> { static constexpr double v = 0x1p512; };
+template <class R> __device__ __forceinline__ R capped_inverse(R dk) {
+    const R r = R(1) / dk;
+    return r > InvCap<R>::v ? InvCap<R>::v : (r < -InvCap<R>::v ? -InvCap<R>::v : r);
+}
 template <class R> __device__ __forceinline__ void bvh_begin(BvhQuery<R>& q, V<R> o, V<R> d, uint32_t n_inner) {
-    q.inv = {R(1) / d.x, R(1) / d.y, R(1) / d.z};
+    q.inv = {capped_inverse<R>(d.x), capped_inverse<R>(d.y), capped_inverse<R>(d.z)};
     q.noi = {-(o.x * q.inv.x), -(o.y * q.inv.y), -(o.z * q.inv.z)};
     q.eb = Slack<R>::u4 * ((finite_abs(q.noi.x) + finite_abs(q.noi.y)) + finite_abs(q.noi.z));
     const double ddx = d.x, ddy = d.y, ddz = d.z;
@@ -1049,9 +1063,9 @@ template <class R> __device__ __forceinline__ void bvh_begin(BvhQuery<R>& q, V<R
 // Slab test (AABB.hit, src/hit.zig:70-98) with 1/d and −o/d hoisted: each plane distance is one fma.  It is
 // CONSERVATIVE — rounding never culls a box the f64 narrow phase would hit: fm(plane, inv, noi) differs from
 // (plane − o)·inv by at most u·(|t| + |o·inv|) (the rounding of noi and of the fma), covered on the exit side by the
-// relative slack 1 + 4 ulp and the absolute slack eb = 4·u·Σ|o_k·inv_k|.  A direction component of 0 makes that axis
-// ±inf or NaN, which min / max then ignore: the axis is not tested (conservative again).  Returns the entry distance
-// through `t0`.
+// relative slack 1 + 4 ulp and the absolute slack eb = 4·u·Σ|o_k·inv_k|.  A direction component of 0 reaches here as
+// ±1/K (bvh_begin): the axis yields huge finite distances of the right sign — the whole line when o lies in the slab,
+// nothing when it lies outside.  Returns the entry distance through `t0`.
 template <class R>
 __device__ __forceinline__ bool bvh_box_hit(typename VecOf<R>::type lo, typename VecOf<R>::type hi, const BvhQuery<R>& q,
                                             R tmin, R& t0) {

@@ -141,6 +141,37 @@ def random_boxes(rng, n):
     return rec
 
 
+def axis_parallel_boxes(rng, n):
+    """Rays with one or two direction components EXACTLY zero (±0) against boxes on either side of the origin and
+    across it: the case where a reciprocal of ±inf turns one slab distance into −inf and the other into NaN.  The
+    origin never lies on a box plane (the reference's own test is 0/0 there).  Returns (records, geometric truth,
+    rows whose ray runs parallel to a slab it is OUTSIDE of by at least 0.1: never a hit)."""
+    rec = blank(n)
+    lo = f32r(rng.uniform(-10, 6, (n, 3)))
+    hi = f32r(lo + rng.uniform(0.5, 8, (n, 3)))
+    inside = rng.random((n, 3)) < 0.7
+    o = np.where(inside, lo + (hi - lo) * rng.uniform(0.05, 0.95, (n, 3)),
+                 np.where(rng.random((n, 3)) < 0.5, lo - rng.uniform(0.1, 5, (n, 3)), hi + rng.uniform(0.1, 5, (n, 3))))
+    o = f32r(o)
+    aim = lo + (hi - lo) * rng.uniform(-0.3, 1.3, (n, 3))
+    d = f32r((aim - o) * rng.uniform(0.1, 3, (n, 1)))
+    nz = rng.integers(1, 3, n)  # how many components are zero
+    for i in range(n):
+        ax = rng.permutation(3)[: nz[i]]
+        d[i, ax] = rng.choice([0.0, -0.0], len(ax))
+    rec[:, 0:3], rec[:, 3:6], rec[:, 6:9], rec[:, 9:12] = lo, hi, o, d
+    rec[:, 12], rec[:, 13] = 1e-3, np.inf
+    # geometric truth: a parallel axis is satisfied iff o lies strictly inside the slab; the others by exact intervals
+    with np.errstate(divide="ignore", invalid="ignore"):
+        a, b = (lo - o) / d, (hi - o) / d
+    par = d == 0
+    ok_par = ((o > lo) & (o < hi)) | ~par
+    t_in = np.where(par, -np.inf, np.minimum(a, b)).max(1)
+    t_out = np.where(par, np.inf, np.maximum(a, b)).min(1)
+    truth = ok_par.all(1) & (t_out > np.maximum(t_in, 1e-3))
+    return rec, truth, ~ok_par.all(1)
+
+
 def random_checkers(rng, n):
     rec = blank(n)
     rec[:, 0:3] = f32r(rng.uniform(-50, 50, (n, 3)))

@@ -45,9 +45,10 @@ def random_scene(seed):
     return t
 
 
-@pytest.mark.parametrize("seed", range(12))
+# 1000..1011, and three scenes on which the BVH walk once lost hits to a zero direction component (tests/test_kat_cpu.py)
+@pytest.mark.parametrize("seed", list(range(1000, 1012)) + [5003, 5008, 5010])
 def test_random_scene_parity(gpu, oracle, seed):
-    t = random_scene(1000 + seed)
+    t = random_scene(seed)
     for trav in (capi.TRAVERSAL_LINEAR, capi.TRAVERSAL_BVH):
         for prec in (capi.PRECISION_F32, capi.PRECISION_F64):
             t.set_gpu(traversal=trav, precision=prec)

@@ -201,6 +201,47 @@ def test_refract_reflectance_checker_background_box_mode_b_equals_mode_a(oracle)
     assert 0.2 < a.mean() < 0.8
 
 
+def test_box_test_with_zero_direction_components(oracle):
+    """A direction component of exactly 0 (a diffuse scatter produces one about once in 1e5 bounces at |p| = 50): with
+    1/d = ±inf the one-FMA slab distance of a box that straddles 0 is −inf for one plane and NaN for the other, and the
+    box was culled although the ray lies inside its slab (found by tools/fuzz_more.py as flat list != BVH).  The
+    reciprocal is held to ±2^64 / ±2^512: mode B never misses a box the geometry hits, nor one mode A's literal
+    reference test hits."""
+    rng = np.random.default_rng(12)
+    rec, truth, beside = K.axis_parallel_boxes(rng, 200_000)
+    a = oracle.kat_a(capi.KAT_BOX_HIT, rec)[:, 0]
+    assert (a[truth] == 1).all() and 0.1 < truth.mean() < 0.9 and beside.mean() > 0.2
+    for prec in (F64, F32):
+        b = oracle.kat_b(capi.KAT_BOX_HIT, rec, prec)[:, 0]
+        assert (b[truth] == 1).all() and (b[a == 1] == 1).all()
+        # still a test on the parallel axis: a ray that runs beside the slab is culled.  (On the OTHER axes such a ray
+        # is no longer culled: the absolute slack carries 4u·K·|o_k| — the price of staying conservative for one ray in
+        # 1e5; it then visits every box whose parallel slabs contain it.)
+        assert (b[beside] == 0).all()
+    # the hand case: box [-1, 2]^3 around the origin, ray inside it along +z with d.x = d.y = 0
+    one = K.blank(4)
+    one[:, 0:3], one[:, 3:6] = -1.0, 2.0
+    one[:, 6:9] = [[0.5, 0.5, -5.0], [-0.5, 0.5, -5.0], [0.5, 2.5, -5.0], [-3.0, 0.5, -5.0]]
+    one[:, 9:12] = [[0.0, 0.0, 1.0], [-0.0, 0.0, 2.0], [0.0, 0.0, 1.0], [0.0, -0.0, 1.0]]
+    one[:, 12], one[:, 13] = 1e-3, np.inf
+    for prec in (F64, F32):
+        assert oracle.kat_b(capi.KAT_BOX_HIT, one, prec)[:, 0].tolist() == [1, 1, 0, 0]
+
+
+def test_flat_list_equals_bvh_on_the_fuzz_scenes_that_found_the_zero_component_bug(oracle):
+    """tests/test_fuzz_gpu.random_scene seeds on which mode B's BVH walk lost hits of the ground sphere (rays inside a
+    dielectric r = 500 ground with an exactly-zero direction component): flat list and BVH agree bit for bit."""
+    from test_fuzz_gpu import random_scene
+    for seed in (5003, 5008, 5010):
+        t = random_scene(seed)
+        got = {}
+        for trav in (capi.TRAVERSAL_LINEAR, capi.TRAVERSAL_BVH):
+            t.set_gpu(traversal=trav, precision=F32)
+            got[trav] = oracle.render_b(t.scene_desc(), t.camera_desc(), t.params())
+        a, b = got[capi.TRAVERSAL_LINEAR], got[capi.TRAVERSAL_BVH]
+        assert np.array_equal(a[0], b[0], equal_nan=True) and a[1].segments == b[1].segments, seed
+
+
 def test_triangle_mode_b_vs_mode_a(oracle):
     """Build-defined primitive (parity unpinned): f64 mode B decides like the literal f64 Möller–Trumbore except at
     edges within rounding; the f32 decision differs there by construction (the filter IS the test)."""

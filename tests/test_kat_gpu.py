@@ -41,6 +41,7 @@ def test_device_functions_equal_mode_b_bit_for_bit(gpu, oracle, prec):
         (capi.KAT_REFLECTANCE, refl),
         (capi.KAT_GET_RAY, K.random_get_rays(rng, 50_000, cam)),
         (capi.KAT_BOX_HIT, K.random_boxes(rng, 100_000)),
+        (capi.KAT_BOX_HIT, K.axis_parallel_boxes(rng, 50_000)[0]),  # direction components of exactly ±0
         (capi.KAT_SPHERE_HIT, K.random_sphere_hits(rng, 100_000)),
         (capi.KAT_SPHERE_HIT, K.random_sphere_hits(rng, 100_000, big=True)),
         (capi.KAT_SCATTER, K.random_scatters(rng, 100_000)),
@@ -52,6 +53,15 @@ def test_device_functions_equal_mode_b_bit_for_bit(gpu, oracle, prec):
         got, want = gpu.kat(op, rec, prec), oracle.kat_b(op, rec, prec)
         same = (got == want) | (np.isnan(got) & np.isnan(want))
         assert same.all(), (op, prec, int((~same).any(1).sum()), np.flatnonzero((~same).any(1))[:5].tolist())
+
+
+@pytest.mark.parametrize("prec", [F32, F64])
+def test_device_box_test_with_zero_direction_components(gpu, prec):
+    """The device's slab test never culls a box whose slab the axis-parallel ray lies in (see the CPU test of the same
+    name for the history)."""
+    rec, truth, beside = K.axis_parallel_boxes(np.random.default_rng(12), 200_000)
+    got = gpu.kat(capi.KAT_BOX_HIT, rec, prec)[:, 0]
+    assert (got[truth] == 1).all() and (got[beside] == 0).all()
 
 
 def test_conservative_filter_on_the_device(gpu, oracle):
