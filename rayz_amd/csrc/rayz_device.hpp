@@ -1044,12 +1044,14 @@ template <class R> __device__ __forceinline__ R finite_abs(R v) { return ab(v) <
 template <class R> struct InvCap;
 template <> struct InvCap<float> { static constexpr float v = 0x1p64f; };
 template <> struct InvCap<double> { static constexpr double v = 0x1p512; };
-template <class R> __device__ __forceinline__ R capped_inverse(R dk) {
-    const R r = R(1) / dk;
-    return r > InvCap<R>::v ? InvCap<R>::v : (r < -InvCap<R>::v ? -InvCap<R>::v : r);
+__device__ __forceinline__ float capped_inverse(float dk) { // (one v_med3_f32)
+    return __builtin_amdgcn_fmed3f(1.0f / dk, -InvCap<float>::v, InvCap<float>::v);
+}
+__device__ __forceinline__ double capped_inverse(double dk) {
+    return __builtin_fmin(__builtin_fmax(1.0 / dk, -InvCap<double>::v), InvCap<double>::v);
 }
 template <class R> __device__ __forceinline__ void bvh_begin(BvhQuery<R>& q, V<R> o, V<R> d, uint32_t n_inner) {
-    q.inv = {capped_inverse<R>(d.x), capped_inverse<R>(d.y), capped_inverse<R>(d.z)};
+    q.inv = {capped_inverse(d.x), capped_inverse(d.y), capped_inverse(d.z)};
     q.noi = {-(o.x * q.inv.x), -(o.y * q.inv.y), -(o.z * q.inv.z)};
     q.eb = Slack<R>::u4 * ((finite_abs(q.noi.x) + finite_abs(q.noi.y)) + finite_abs(q.noi.z));
     const double ddx = d.x, ddy = d.y, ddz = d.z;
