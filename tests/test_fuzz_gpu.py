@@ -45,6 +45,65 @@ def random_scene(seed):
     return t
 
 
+def axis_scene(seed):
+    """Second generator: the geometry that makes exact zeros and ties — axis-aligned quads and boxes on integer
+    coordinates, spheres centred on lattice points (some far from the origin, where a small scatter offset is absorbed
+    by rounding), mirrors and glass, a camera that may look straight down an axis."""
+    rng = np.random.default_rng(seed)
+    far = float(rng.choice([0.0, 0.0, 100.0, 3000.0]))  # offset of the whole scene along x
+    axis_cam = rng.random() < 0.5
+    look_from = np.array([far, 2.0, 8.0]) if axis_cam else rng.uniform(-6, 6, 3) + np.array([far, 3.0, 0])
+    look_at = np.array([far, 2.0, 0.0]) if axis_cam else np.array([far, 1.0, 0.0]) + rng.uniform(-1, 1, 3)
+    t = tracer.Tracer.init(int(rng.integers(24, 64)), float(rng.uniform(20, 70)), float(rng.uniform(2, 10)),
+                           float(rng.choice([0.0, 0.0, 1.0])), look_from, look_at, (0, 1, 0), seed=seed)
+    P = t.pool
+    tex = [P.add_solid_texture(rng.uniform(0.05, 0.95, 3)) for _ in range(3)]
+    tex.append(P.add_checker_texture(1.0, tex[0], tex[1]))
+    mats = [P.add_diffuse(int(rng.choice(tex)), 2), P.add_diffuse(int(rng.choice(tex)), int(rng.integers(0, 3))),
+            P.add_metallic(tex[0], 0.0), P.add_metallic(tex[1], 0.3), P.add_dielectric(1.5), P.add_dielectric(1 / 1.5)]
+    P.add_sphere((far, -500, 0), 500.0, int(rng.choice(mats)))  # the ground: sometimes glass or a mirror
+    for _ in range(int(rng.integers(0, 20))):
+        c = np.round(rng.uniform(-4, 4, 3))
+        c[1] = abs(c[1]) + 1.0
+        c[0] += far
+        v = (0, 0, 0) if rng.random() < 0.6 else (0, float(rng.choice([0.5, -0.25, 1.0])), 0)
+        P.add_sphere(c, float(rng.choice([0.5, 1.0, 0.25])), int(rng.choice(mats)), velocity=v)
+
+    def quad(a, e1, e2, m):
+        P.add_triangle(a, a + e1, a + e1 + e2, m)
+        P.add_triangle(a, a + e1 + e2, a + e2, m)
+
+    for _ in range(int(rng.integers(0, 6))):  # axis-aligned boxes and single quads
+        lo = np.round(rng.uniform(-4, 3, 3))
+        lo[1] = abs(lo[1])
+        lo[0] += far
+        sz = rng.choice([1.0, 2.0, 0.5], 3)
+        m = int(rng.choice(mats))
+        ex, ey, ez = np.array([sz[0], 0, 0]), np.array([0, sz[1], 0]), np.array([0, 0, sz[2]])
+        if rng.random() < 0.5:
+            quad(lo, ex, ey, m), quad(lo + ez, ex, ey, m), quad(lo, ex, ez, m), quad(lo + ey, ex, ez, m)
+            quad(lo, ey, ez, m), quad(lo + ex, ey, ez, m)
+        else:
+            quad(lo, *[(ex, ey), (ex, ez), (ey, ez)][int(rng.integers(0, 3))], m)
+    t.samples_per_px = int(rng.integers(1, 16))
+    t.max_bounces = int(rng.integers(2, 40))
+    t.set_gpu(render_seed=int(rng.integers(0, 2 ** 62)), chunk_spp=int(rng.choice([0, 1, 16])))
+    return t
+
+
+@pytest.mark.parametrize("seed", range(200, 208))
+def test_axis_scene_parity(gpu, oracle, seed):
+    t = axis_scene(seed)
+    for trav in (capi.TRAVERSAL_LINEAR, capi.TRAVERSAL_BVH):
+        for prec in (capi.PRECISION_F32, capi.PRECISION_F64):
+            t.set_gpu(traversal=trav, precision=prec)
+            scene, cam, p = t.scene_desc(), t.camera_desc(), t.params()
+            got, gst = gpu.render_host(scene, cam, p)
+            want, ost = oracle.render_b(scene, cam, p)
+            assert_images_equal(got, want, f"axis scene {seed} traversal {trav} precision {prec}")
+            assert gst.segments == ost.segments
+
+
 # 1000..1011, and three scenes on which the BVH walk once lost hits to a zero direction component (tests/test_kat_cpu.py)
 @pytest.mark.parametrize("seed", list(range(1000, 1012)) + [5003, 5008, 5010])
 def test_random_scene_parity(gpu, oracle, seed):

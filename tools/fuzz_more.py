@@ -1,19 +1,19 @@
 #!/usr/bin/env python3
 """One-off: the random-scene parity fuzz of tests/test_fuzz_gpu.py over many more seeds (GPU vs oracle, bit for bit,
-flat list and BVH, f32 and f64).  usage: fuzz_more.py <first_seed> <count>"""
+flat list and BVH, f32 and f64).  usage: fuzz_more.py <first_seed> <count> [axis]   (axis: the axis-aligned generator)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from oracle import binding as oracle
 from rayz_amd import capi, render
-from test_fuzz_gpu import random_scene
+from test_fuzz_gpu import random_scene, axis_scene
 
 render.init(0); oracle.load()
 first, count = int(sys.argv[1]), int(sys.argv[2])
 bad = 0
 for seed in range(first, first + count):
-    t = random_scene(seed)
+    t = (axis_scene if len(sys.argv) > 3 and sys.argv[3] == 'axis' else random_scene)(seed)
     for trav in (capi.TRAVERSAL_LINEAR, capi.TRAVERSAL_BVH):
         for prec in (capi.PRECISION_F32, capi.PRECISION_F64):
             t.set_gpu(traversal=trav, precision=prec)
