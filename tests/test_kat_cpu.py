@@ -231,9 +231,10 @@ def test_box_test_with_zero_direction_components(oracle):
 def test_flat_list_equals_bvh_on_the_fuzz_scenes_that_found_the_zero_component_bug(oracle):
     """tests/test_fuzz_gpu.random_scene seeds on which mode B's BVH walk lost hits of the ground sphere (rays inside a
     dielectric r = 500 ground with an exactly-zero direction component): flat list and BVH agree bit for bit."""
-    from test_fuzz_gpu import random_scene
-    for seed in (5003, 5008, 5010):
-        t = random_scene(seed)
+    from test_fuzz_gpu import axis_scene, random_scene
+    scenes = [random_scene(s) for s in (5003, 5008, 5010)] + [random_scene(s) for s in range(7000, 7030)] + \
+             [axis_scene(s) for s in range(900, 920)]
+    for seed, t in enumerate(scenes):
         got = {}
         for trav in (capi.TRAVERSAL_LINEAR, capi.TRAVERSAL_BVH):
             t.set_gpu(traversal=trav, precision=F32)

@@ -98,7 +98,7 @@ def test_gpu_small_mesh_flat_list_and_bvh(gpu, oracle):
         assert_images_equal(got, want, f"mesh 20x20 traversal {trav}")
         _check_counters(gst, ost)
         imgs.append(got)
-    assert (np.abs(imgs[0] - imgs[1]).max(axis=2) > 0).mean() < 2e-3  # same hits up to grazing box-test cases
+    assert np.array_equal(imgs[0], imgs[1])  # the same hits: the box test is conservative
 
 
 @pytest.mark.gpu
