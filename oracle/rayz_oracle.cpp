@@ -644,7 +644,7 @@ template <class R> struct SceneB {
     // BVH traversal: the mode-A tree (src/hit.zig:130-161) in depth-first pre-order with skip links; boxes
     // narrowed outward to R
     struct Node {
-        R lo[3], hi[3];
+        float lo[3], hi[3]; // f32 for both precisions, rounded outward: the box test only culls
         u32 skip, first, count;
     };
     std::vector<Node> nodes;
@@ -774,7 +774,7 @@ template <class R> static void buildBvh(const RayzSceneDesc& d, SceneB<R>& s) {
     for (size_t i = 0; i < t.nodes.size(); ++i) {
         const A::BVH::Node& n = t.nodes[i];
         typename SceneB<R>::Node o;
-        for (int k = 0; k < 3; ++k) o.lo[k] = roundDown<R>(n.bbox.low.at(k)), o.hi[k] = roundUp<R>(n.bbox.high.at(k));
+        for (int k = 0; k < 3; ++k) o.lo[k] = roundDown<float>(n.bbox.low.at(k)), o.hi[k] = roundUp<float>(n.bbox.high.at(k));
         o.skip = subtreeEnd(t, (int)i);
         o.first = n.left < 0 ? (u32)n.starti : 0;
         o.count = n.left < 0 ? (u32)(n.endi - n.starti) : 0;
@@ -1022,35 +1022,40 @@ template <class R> static void triAccept(R filt, V<R> v0, V<R> e1, V<R> e2, V<R>
         ibest = prim;
     }
 }
-// slab test, src/hit.zig:70-98, with 1/d and −o/d hoisted (one fma per plane) and a relative (1 + 4 ulp) plus absolute
-// (4·u·Σ|o_k / d_k|) slack on the exit side: never culls a box the f64 narrow phase would hit
+// slab test, src/hit.zig:70-98, with 1/d and −o/d hoisted (one fma per plane), IN F32 FOR BOTH PRECISIONS, and a relative
+// plus an absolute slack on the exit side: never culls a box the f64 narrow phase would hit.  R = float:
+// 1 + 4 ulp and 4·u·Σ|o_k / d_k|; R = double (the ray narrowed to f32: d_k rounded, −o·inv from the f64 origin rounded
+// once): 1 + 8 ulp and 8·u·Σ.  Reciprocals are held to ±2^64: a zero direction component must not reach the test as
+// ±inf — one plane of a box that straddles 0 then gives −inf, the other NaN, and max(−inf, NaN) = −inf culls a box the
+// ray lies inside.
 template <class R> struct SlabRay {
-    V<R> inv, noi;
-    R eb;
+    V<float> inv, noi;
+    float eb;
 };
 template <class R> static SlabRay<R> slabRay(V<R> o, V<R> d) {
     SlabRay<R> s;
-    // reciprocals held to ±K (2^64 / 2^512): a zero direction component must not reach the test as ±inf — one plane of a
-    // box that straddles 0 then gives −inf, the other NaN, and max(−inf, NaN) = −inf culls a box the ray lies inside
-    const R K = sizeof(R) == 4 ? (R)0x1p64 : (R)0x1p512;
-    auto inv = [K](R dk) {
-        const R r = R(1) / dk;
-        return r > K ? K : (r < -K ? -K : r);
+    auto clampf = [](float v, float lim) { return v > lim ? lim : (v < -lim ? -lim : v); };
+    auto inv = [&](R dk) {
+        float f = (float)dk;
+        if (sizeof(R) == 8) f = clampf(f, 0x1p100f); // beyond f32's range the reciprocal would be 0
+        return clampf(1.0f / f, 0x1p64f);
     };
     s.inv = {inv(d.x), inv(d.y), inv(d.z)};
-    s.noi = {-(o.x * s.inv.x), -(o.y * s.inv.y), -(o.z * s.inv.z)};
-    auto fa = [](R v) { return std::fabs(v) <= (R)3.0e38 ? std::fabs(v) : R(0); };
-    const R u4 = R(4) * (std::numeric_limits<R>::epsilon() / R(2));
-    s.eb = u4 * ((fa(s.noi.x) + fa(s.noi.y)) + fa(s.noi.z));
+    s.noi = {(float)(-(o.x * (R)s.inv.x)), (float)(-(o.y * (R)s.inv.y)), (float)(-(o.z * (R)s.inv.z))};
+    auto fa = [](float v) { return std::fabs(v) <= 3.0e38f ? std::fabs(v) : 0.0f; };
+    const float u = std::numeric_limits<float>::epsilon() / 2.0f;
+    s.eb = (sizeof(R) == 8 ? 8.0f : 4.0f) * u * ((fa(s.noi.x) + fa(s.noi.y)) + fa(s.noi.z));
     return s;
 }
-template <class R> static bool boxHit(const R* lo, const R* hi, const SlabRay<R>& s, R tmin, R tbest, R& t0) {
-    const R slack = R(1) + R(4) * std::numeric_limits<R>::epsilon();
-    const R ax = fm(lo[0], s.inv.x, s.noi.x), bx = fm(hi[0], s.inv.x, s.noi.x);
-    const R ay = fm(lo[1], s.inv.y, s.noi.y), by = fm(hi[1], s.inv.y, s.noi.y);
-    const R az = fm(lo[2], s.inv.z, s.noi.z), bz = fm(hi[2], s.inv.z, s.noi.z);
-    t0 = std::fmax(std::fmax(std::fmin(ax, bx), std::fmin(ay, by)), std::fmax(std::fmin(az, bz), tmin));
-    const R t1 = std::fmin(std::fmin(std::fmax(ax, bx), std::fmax(ay, by)), std::fmin(std::fmax(az, bz), tbest));
+// tmin rounded DOWN to f32, tbest rounded UP
+template <class R> static bool boxHit(const float* lo, const float* hi, const SlabRay<R>& s, R tmin, R tbest, float& t0) {
+    const float slack = 1.0f + (sizeof(R) == 8 ? 8.0f : 4.0f) * std::numeric_limits<float>::epsilon();
+    const float tmin32 = roundDown<float>((double)tmin), tb32 = roundUp<float>((double)tbest);
+    const float ax = fm(lo[0], s.inv.x, s.noi.x), bx = fm(hi[0], s.inv.x, s.noi.x);
+    const float ay = fm(lo[1], s.inv.y, s.noi.y), by = fm(hi[1], s.inv.y, s.noi.y);
+    const float az = fm(lo[2], s.inv.z, s.noi.z), bz = fm(hi[2], s.inv.z, s.noi.z);
+    t0 = std::fmax(std::fmax(std::fmin(ax, bx), std::fmin(ay, by)), std::fmax(std::fmin(az, bz), tmin32));
+    const float t1 = std::fmin(std::fmin(std::fmax(ax, bx), std::fmax(ay, by)), std::fmin(std::fmax(az, bz), tb32));
     return fm(t1, slack, s.eb) >= t0;
 }
 
@@ -1124,7 +1129,7 @@ static PathResult<R> tracePath(const SceneB<R>& sc, const CamB<R>& cam, const Ra
             while (idx < nn) {
                 const typename SceneB<R>::Node& nd = sc.nodes[idx];
                 res.node_tests++;
-                R t0;
+                float t0;
                 u32 next = nd.skip;
                 if (boxHit<R>(nd.lo, nd.hi, slab, tmin, tbest, t0)) {
                     if (nd.count == 0) next = idx + 1;
@@ -1353,8 +1358,9 @@ template <class R> static void katB(uint32_t op, const double* a, double* r) {
     }
     case RAYZ_KAT_BOX_HIT: {
         const SlabRay<R> slab = slabRay<R>(v3(6), v3(9));
-        const R lo[3] = {(R)a[0], (R)a[1], (R)a[2]}, hi[3] = {(R)a[3], (R)a[4], (R)a[5]};
-        R t0;
+        const float lo[3] = {roundDown<float>(a[0]), roundDown<float>(a[1]), roundDown<float>(a[2])};
+        const float hi[3] = {roundUp<float>(a[3]), roundUp<float>(a[4]), roundUp<float>(a[5])};
+        float t0;
         r[0] = boxHit<R>(lo, hi, slab, (R)a[12], (R)a[13], t0) ? 1.0 : 0.0;
         r[1] = (double)t0;
         break;

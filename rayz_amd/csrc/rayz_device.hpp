@@ -72,7 +72,8 @@ template <class R> struct DevScene {
     const r4* tri;           // [3 * (nt_pad + kTriGroup)]
     uint32_t nt_pad, n_triangles;
     // BVH traversal (RAYZ_TRAVERSAL_BVH): the reference's tree in depth-first pre-order, DESIGN.md §6
-    const r4* bvh_nodes;     // [4 * n_inner] per INNER node, its two children's boxes (one 64-B fetch, two slab tests):
+    const f4* bvh_nodes;     // [4 * n_inner] per INNER node, its two children's boxes IN F32 FOR BOTH PRECISIONS (the box
+                             // test only culls, §4.8) — one 64-B fetch, two slab tests:
                              //   {L.lo, bits(L.id)}, {L.hi, bits(L.leaf)}, {R.lo, bits(R.id)}, {R.hi, bits(R.leaf)}
                              //   id = the child's inner-node index; leaf = first << 4 | type1 << 3 | type0 << 2 | count
                              //   (0 for an inner child)
@@ -1006,21 +1007,13 @@ __device__ __forceinline__ float min_bound(float x, float bound) {
     asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(bound));
     return r;
 }
-__device__ __forceinline__ double max_bound(double x, double bound) {
-    double r;
-    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(bound));
-    return r;
-}
-__device__ __forceinline__ double min_bound(double x, double bound) {
-    double r;
-    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(bound));
-    return r;
-}
 
 template <class R> struct BvhQuery {
-    V<R> inv;       // 1 / d per component
-    V<R> noi;       // −o · inv per component: a slab distance is ONE fma, t = fm(plane, inv, noi)
-    R eb;           // absolute slack of the slab test: 4·u·Σ|noi_k| (finite components only)
+    // the slab test runs in f32 whatever R is: it only culls, and stays conservative under the conversion (§4.8)
+    V<float> inv;   // 1 / d per component (capped, bvh_begin)
+    V<float> noi;   // −o · inv per component: a slab distance is ONE fma, t = fm(plane, inv, noi)
+    float eb;       // absolute slack of the slab test: Σ|noi_k| (finite components only) times BoxSlack<R>::abs
+    float tb32;     // tbest as the box steps see it: rounded UP to f32 (refreshed before every run of box steps)
     double inv_a2;  // 1 / (d·d) in f64 for the narrow phase
     R tbest;
     int ibest;      // hittable index
@@ -1029,34 +1022,43 @@ template <class R> struct BvhQuery {
     uint32_t sp;    // index of the stack's top entry; entry 0 is a kBvhDone sentinel, so popping an empty stack ends the walk
 };
 
-template <class R> struct Slack; // relative slack of the slab test: 1 + 4 ulp
-template <> struct Slack<float> { static constexpr float v = 1.0f + 4.0f * 1.1920929e-07f, u4 = 4.0f * 5.9604645e-08f; };
-template <> struct Slack<double> { static constexpr double v = 1.0 + 4.0 * 2.220446049250313e-16, u4 = 4.0 * 1.1102230246251565e-16; };
+// Slack of the f32 slab test.  R = float: relative 1 + 4 ulp (= 8u, u = 2^-24) and absolute 4u·Σ|noi|, against a need of
+// 4u and 2u (§4.8).  R = double: the ray is narrowed to f32 first (d_k rounded: one more u on inv; noi from the f64
+// origin and the f32 inv, rounded once), need 6u and 2u: 1 + 8 ulp and 8u·Σ|noi|.
+template <class R> struct BoxSlack;
+template <> struct BoxSlack<float> { static constexpr float rel = 1.0f + 4.0f * 1.1920929e-07f, abs = 4.0f * 5.9604645e-08f; };
+template <> struct BoxSlack<double> { static constexpr float rel = 1.0f + 8.0f * 1.1920929e-07f, abs = 8.0f * 5.9604645e-08f; };
 
-template <class R> __device__ __forceinline__ R finite_abs(R v) { return ab(v) <= (R)3.0e38 ? ab(v) : R(0); } // 0 for ±inf / NaN
-// 1 / d_k, held to ±K (2^64 for f32, 2^512 for f64).  A direction component of 0 (or so small that its reciprocal
-// overflows) must not reach the slab test as ±inf: fm(plane, ±inf, −o·(±inf)) is −inf for one plane of a box that
-// straddles 0 and NaN for the other, and max(−inf, NaN) = −inf then culls a box the ray lies inside.  (Such
-// directions are not exotic: a diffuse scatter at |p_k| = 50 returns exactly 0 in one component about once in 10^5
-// bounces, when the offset is absorbed by the rounding of p_k + r_k.)  With the clamp the ray is treated as one whose
-// component is 1 / K: finite distances of the right sign, and the absolute slack eb — which then carries K·|o_k| —
-// covers their rounding.
-template <class R> struct InvCap;
-template <> struct InvCap<float> { static constexpr float v = 0x1p64f; };
-template <> struct InvCap<double> { static constexpr double v = 0x1p512; };
-__device__ __forceinline__ float capped_inverse(float dk) { // (one v_med3_f32)
-    return __builtin_amdgcn_fmed3f(1.0f / dk, -InvCap<float>::v, InvCap<float>::v);
-}
-__device__ __forceinline__ double capped_inverse(double dk) {
-    return __builtin_fmin(__builtin_fmax(1.0 / dk, -InvCap<double>::v), InvCap<double>::v);
+__device__ __forceinline__ float finite_abs(float v) { return ab(v) <= 3.0e38f ? ab(v) : 0.0f; } // 0 for ±inf / NaN
+__device__ __forceinline__ float round_up_f32(float v) { return v; }
+__device__ __forceinline__ float round_up_f32(double v) { return __double2float_ru(v); }
+__device__ __forceinline__ float round_down_f32(float v) { return v; }
+__device__ __forceinline__ float round_down_f32(double v) { return __double2float_rd(v); }
+// 1 / d_k, held to ±K = ±2^64.  A direction component of 0 (or so small that its reciprocal overflows) must not reach
+// the slab test as ±inf: fm(plane, ±inf, −o·(±inf)) is −inf for one plane of a box that straddles 0 and NaN for the
+// other, and max(−inf, NaN) = −inf then culls a box the ray lies inside.  (Such directions are not exotic: a diffuse
+// scatter at |p_k| = 50 returns exactly 0 in one component about once in 10^5 bounces, when the offset is absorbed by the
+// rounding of p_k + r_k.)  With the clamp the ray is treated as one whose component is 1 / K: finite distances of the
+// right sign, and the absolute slack eb — which then carries K·|o_k| — covers their rounding.
+constexpr float kInvCap = 0x1p64f;
+__device__ __forceinline__ float capped_inverse(float dk) { // (one v_med3_f32 behind the division)
+    return __builtin_amdgcn_fmed3f(1.0f / dk, -kInvCap, kInvCap);
 }
 template <class R> __device__ __forceinline__ void bvh_begin(BvhQuery<R>& q, V<R> o, V<R> d, uint32_t n_inner) {
-    q.inv = {capped_inverse(d.x), capped_inverse(d.y), capped_inverse(d.z)};
-    q.noi = {-(o.x * q.inv.x), -(o.y * q.inv.y), -(o.z * q.inv.z)};
-    q.eb = Slack<R>::u4 * ((finite_abs(q.noi.x) + finite_abs(q.noi.y)) + finite_abs(q.noi.z));
+    if constexpr (sizeof(R) == 8) { // d_k narrowed to f32 first; a component beyond f32's range would make inv 0: held to ±2^100
+        q.inv = {capped_inverse(__builtin_amdgcn_fmed3f((float)d.x, -0x1p100f, 0x1p100f)),
+                 capped_inverse(__builtin_amdgcn_fmed3f((float)d.y, -0x1p100f, 0x1p100f)),
+                 capped_inverse(__builtin_amdgcn_fmed3f((float)d.z, -0x1p100f, 0x1p100f))};
+    } else {
+        q.inv = {capped_inverse(d.x), capped_inverse(d.y), capped_inverse(d.z)};
+    }
+    // −o·inv with the origin at full precision, rounded once
+    q.noi = {(float)(-(o.x * (R)q.inv.x)), (float)(-(o.y * (R)q.inv.y)), (float)(-(o.z * (R)q.inv.z))};
+    q.eb = BoxSlack<R>::abs * ((finite_abs(q.noi.x) + finite_abs(q.noi.y)) + finite_abs(q.noi.z));
     const double ddx = d.x, ddy = d.y, ddz = d.z;
     q.inv_a2 = 1.0 / fm(ddz, ddz, fm(ddy, ddy, ddx * ddx));
     q.tbest = (R)__builtin_inff();
+    q.tb32 = __builtin_inff();
     q.ibest = -1;
     q.cur = n_inner ? 0u : kBvhDone;
     q.sp = 0;
@@ -1065,20 +1067,21 @@ template <class R> __device__ __forceinline__ void bvh_begin(BvhQuery<R>& q, V<R
 // Slab test (AABB.hit, src/hit.zig:70-98) with 1/d and −o/d hoisted: each plane distance is one fma.  It is
 // CONSERVATIVE — rounding never culls a box the f64 narrow phase would hit: fm(plane, inv, noi) differs from
 // (plane − o)·inv by at most u·(|t| + |o·inv|) (the rounding of noi and of the fma), covered on the exit side by the
-// relative slack 1 + 4 ulp and the absolute slack eb = 4·u·Σ|o_k·inv_k|.  A direction component of 0 reaches here as
-// ±1/K (bvh_begin): the axis yields huge finite distances of the right sign — the whole line when o lies in the slab,
-// nothing when it lies outside.  Returns the entry distance through `t0`.
+// relative and the absolute slack (BoxSlack).  A direction component of 0 reaches here as ±1/K (bvh_begin): the axis
+// yields huge finite distances of the right sign — the whole line when o lies in the slab, nothing when it lies outside.
+// `tmin` is the caller's tmin rounded DOWN to f32, q.tb32 tbest rounded UP.  Returns the entry distance through `t0`.
 template <class R>
-__device__ __forceinline__ bool bvh_box_hit(typename VecOf<R>::type lo, typename VecOf<R>::type hi, const BvhQuery<R>& q,
-                                            R tmin, R& t0) {
-    const R ax = fm(lo.x, q.inv.x, q.noi.x), bx = fm(hi.x, q.inv.x, q.noi.x);
-    const R ay = fm(lo.y, q.inv.y, q.noi.y), by = fm(hi.y, q.inv.y, q.noi.y);
-    const R az = fm(lo.z, q.inv.z, q.noi.z), bz = fm(hi.z, q.inv.z, q.noi.z);
+__device__ __forceinline__ bool bvh_box_hit(f4 lo, f4 hi, const BvhQuery<R>& q, float tmin, float& t0) {
+    const float ax = fm(lo.x, q.inv.x, q.noi.x), bx = fm(hi.x, q.inv.x, q.noi.x);
+    const float ay = fm(lo.y, q.inv.y, q.noi.y), by = fm(hi.y, q.inv.y, q.noi.y);
+    const float az = fm(lo.z, q.inv.z, q.noi.z), bz = fm(hi.z, q.inv.z, q.noi.z);
     // (tmin and tbest are never NaN: max_bound / min_bound spare the canonicalising copy fmax / fmin would put in front of
     // every use — two vector instructions per step)
     t0 = mx(mx(mn(ax, bx), mn(ay, by)), max_bound(mn(az, bz), tmin));
-    const R t1 = mn(mn(mx(ax, bx), mx(ay, by)), min_bound(mx(az, bz), q.tbest));
-    return fm(t1, Slack<R>::v, q.eb) >= t0;
+    float tb;
+    if constexpr (sizeof(R) == 4) tb = q.tbest; else tb = q.tb32; // (f32: tbest itself — no second register)
+    const float t1 = mn(mn(mx(ax, bx), mx(ay, by)), min_bound(mx(az, bz), tb));
+    return fm(t1, BoxSlack<R>::rel, q.eb) >= t0;
 }
 
 // Phase N — one step of a lane that holds an inner node: fetch the node's record, slab-test both children, push the
@@ -1088,24 +1091,21 @@ __device__ __forceinline__ bool bvh_box_hit(typename VecOf<R>::type lo, typename
 // top when there is nothing to push, the pop is a read every stepping lane makes.  `stack` is this lane's column of
 // the workgroup's LDS stack (entry s at stack[s * 256]).
 template <class R>
-__device__ __forceinline__ void bvh_node_step(const DevScene<R>& sc, BvhQuery<R>& q, R tmin, uint32_t* stack,
-                                              const typename VecOf<R>::type* top
+__device__ __forceinline__ void bvh_node_step(const DevScene<R>& sc, BvhQuery<R>& q, float tmin, uint32_t* stack
 #ifdef RAYZ_BVH_PROFILE
                                               , unsigned long long& g_fetch_ticks
 #endif
 ) {
-    typedef typename VecOf<R>::type r4;
-    r4 llo, lhi, rlo, rhi;
+    f4 llo, lhi, rlo, rhi;
 #ifdef RAYZ_BVH_PROFILE
     const unsigned long long tl0 = __builtin_amdgcn_s_memtime();
 #endif
-    if constexpr (sizeof(R) == 4) {
-        // Both homes of a node — the LDS copy of the tree's top, global memory for the rest — are read from the SAME
-        // 32-bit offset (index << 6): the lanes of either kind take turns under exec, into the same registers.  Two
-        // vector instructions (a compare, a shift) instead of the nine a flat-address select costs.
-        (void)top;
+    {
+        // Both homes of a node — the LDS copy of the tree's top (at LDS address 0), global memory for the rest — are read
+        // from the SAME 32-bit offset (index << 6): the lanes of either kind take turns under exec, into the same
+        // registers.  Two vector instructions (a compare, a shift) instead of the nine a flat-address select costs.
         const unsigned long long in_top = __ballot(q.cur < sc.bvh_top);
-        const uint32_t off = q.cur << 6; // (the host keeps the node count below 2^26)
+        const uint32_t off = q.cur << 6; // (the host keeps the node count below 2^25)
         unsigned long long saved;
         asm volatile("s_mov_b64 %[sv], exec\n\t"
                      "s_and_b64 exec, %[sv], %[mt]\n\t" // (SCC = some lane: an empty turn is skipped — the memory
@@ -1127,58 +1127,17 @@ __device__ __forceinline__ void bvh_node_step(const DevScene<R>& sc, BvhQuery<R>
                      : [n0] "=&v"(llo), [n1] "=&v"(lhi), [n2] "=&v"(rlo), [n3] "=&v"(rhi), [sv] "=&s"(saved)
                      : [off] "v"(off), [mt] "s"(in_top), [base] "s"(sc.bvh_nodes)
                      : "memory", "scc");
-    } else { // f64: the same two turns, a record is 128 bytes (eight 16-byte halves)
-        (void)top;
-        const unsigned long long in_top = __ballot(q.cur < sc.bvh_top);
-        const uint32_t off = q.cur << 7; // (node count below 2^25 for f64: checked by the host)
-        unsigned long long saved;
-        d2 h0, h1, h2, h3, h4, h5, h6, h7;
-        asm volatile("s_mov_b64 %[sv], exec\n\t"
-                     "s_and_b64 exec, %[sv], %[mt]\n\t"
-                     "s_cbranch_scc0 1f\n\t"
-                     "ds_read_b128 %[h0], %[off]\n\t"
-                     "ds_read_b128 %[h1], %[off] offset:16\n\t"
-                     "ds_read_b128 %[h2], %[off] offset:32\n\t"
-                     "ds_read_b128 %[h3], %[off] offset:48\n\t"
-                     "ds_read_b128 %[h4], %[off] offset:64\n\t"
-                     "ds_read_b128 %[h5], %[off] offset:80\n\t"
-                     "ds_read_b128 %[h6], %[off] offset:96\n\t"
-                     "ds_read_b128 %[h7], %[off] offset:112\n"
-                     "1:\n\t"
-                     "s_andn2_b64 exec, %[sv], %[mt]\n\t"
-                     "s_cbranch_scc0 2f\n\t"
-                     "global_load_dwordx4 %[h0], %[off], %[base]\n\t"
-                     "global_load_dwordx4 %[h1], %[off], %[base] offset:16\n\t"
-                     "global_load_dwordx4 %[h2], %[off], %[base] offset:32\n\t"
-                     "global_load_dwordx4 %[h3], %[off], %[base] offset:48\n\t"
-                     "global_load_dwordx4 %[h4], %[off], %[base] offset:64\n\t"
-                     "global_load_dwordx4 %[h5], %[off], %[base] offset:80\n\t"
-                     "global_load_dwordx4 %[h6], %[off], %[base] offset:96\n\t"
-                     "global_load_dwordx4 %[h7], %[off], %[base] offset:112\n"
-                     "2:\n\t"
-                     "s_mov_b64 exec, %[sv]\n\t"
-                     "s_waitcnt vmcnt(0) lgkmcnt(0)"
-                     : [h0] "=&v"(h0), [h1] "=&v"(h1), [h2] "=&v"(h2), [h3] "=&v"(h3), [h4] "=&v"(h4), [h5] "=&v"(h5),
-                       [h6] "=&v"(h6), [h7] "=&v"(h7), [sv] "=&s"(saved)
-                     : [off] "v"(off), [mt] "s"(in_top), [base] "s"(sc.bvh_nodes)
-                     : "memory", "scc");
-        llo = r4{(R)h0.x, (R)h0.y, (R)h1.x, (R)h1.y};
-        lhi = r4{(R)h2.x, (R)h2.y, (R)h3.x, (R)h3.y};
-        rlo = r4{(R)h4.x, (R)h4.y, (R)h5.x, (R)h5.y};
-        rhi = r4{(R)h6.x, (R)h6.y, (R)h7.x, (R)h7.y};
     }
 #ifdef RAYZ_BVH_PROFILE // time from issuing the node fetch to having it (the wave's own view), accumulated in g_prof_fetch
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     g_fetch_ticks += __builtin_amdgcn_s_memtime() - tl0;
 #endif
-    R tl, tr;
+    float tl, tr;
     const bool hl = bvh_box_hit<R>(llo, lhi, q, tmin, tl), hr = bvh_box_hit<R>(rlo, rhi, q, tmin, tr);
-    // each child's reference rides in its lo.w: an inner index, or kBvhLeafFlag | leaf descriptor.  Nearer child first;
-    // the decisions are kept as lane masks (which child was hit is all that push and pop depend on)
     // Which child was hit decides everything below, so the decisions live as WAVE MASKS in scalar registers (the boolean
     // algebra runs on the scalar unit, which has slack; the vector unit, which has none, spends one v_cndmask per choice):
     const unsigned long long ml = __ballot(hl), mr = __ballot(hr), mlt = __ballot(tr < tl);
     const unsigned long long swap = mr & (~ml | mlt), both = ml & mr, none = ~(ml | mr);
+    // each child's reference rides in its lo.w: an inner index, or kBvhLeafFlag | leaf descriptor.  Nearer child first
     // (a child that was not hit may ride along as `near` or `far`: `none` and `both` decide what is used)
     const uint32_t l = bits(llo.w), r = bits(rlo.w);
     const uint32_t near = mask_select(swap, r, l), far = mask_select(swap, l, r);
@@ -1271,12 +1230,14 @@ template <class R> __global__ __launch_bounds__(256, bvh_waves<R>()) void trace_
     const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     const uint32_t n_nodes = A.sc.bvh_n_nodes;
     const int keep_active = (int)(A.bvh_keep & 0xffu), keep_stepping = (int)((A.bvh_keep >> 8) & 0xffu);
+    const float tmin32 = round_down_f32(A.tmin); // the box steps' tmin
     Pcg32 g{0, 1};
     V<R> o{0, 0, 0}, d{0, 0, 1}, ud{0, 0, 1}, thr{1, 1, 1}, acc{0, 0, 0};
     BvhQuery<R> q;
-    q.inv = {R(1), R(1), R(1)};
-    q.noi = {R(0), R(0), R(0)};
-    q.eb = R(0);
+    q.inv = {1.0f, 1.0f, 1.0f};
+    q.noi = {0.0f, 0.0f, 0.0f};
+    q.eb = 0.0f;
+    q.tb32 = 0.0f;
     q.inv_a2 = 1.0;
     q.tbest = R(0);
     q.ibest = -1;
@@ -1286,7 +1247,7 @@ template <class R> __global__ __launch_bounds__(256, bvh_waves<R>()) void trace_
     // workgroup (A.bvh_top_words u32s; a node's LDS address is its index << 6 for f32), then the per-lane traversal stacks,
     // sized by the launch from the tree's depth: entry s of this lane at stack[256 * s] — conflict-free for any mix of s
     extern __shared__ uint32_t lds_words[];
-    r4* top = (r4*)lds_words;
+    f4* top = (f4*)lds_words;
     uint32_t* stack = lds_words + A.bvh_top_words + threadIdx.x;
     for (uint32_t k = threadIdx.x; k < 4u * A.sc.bvh_top; k += 256u) top[k] = A.sc.bvh_nodes[k];
     stack[0] = kBvhDone; // the sentinel under every lane's stack
@@ -1370,6 +1331,8 @@ template <class R> __global__ __launch_bounds__(256, bvh_waves<R>()) void trace_
         // ---- rounds of (N) box steps, (L) leaf tests, (C) candidate roots ----
         const int n_alive = __popcll(__ballot(alive));
         for (;;) {
+            if constexpr (sizeof(R) == 8) q.tb32 = round_up_f32(q.tbest); // (tbest moves in phases L and C and in the set-up
+                                                                          //  above, never in N)
             for (;;) { // phase N: lanes holding an inner node step; lanes holding a leaf wait
                 const bool can_step = q.cur < kBvhDone;
                 const int n_can = __popcll(__ballot(can_step));
@@ -1380,9 +1343,9 @@ template <class R> __global__ __launch_bounds__(256, bvh_waves<R>()) void trace_
                 px3[0] += __popcll(__ballot((int32_t)q.cur < 0));
                 px3[1] += __popcll(__ballot(alive && q.cur == kBvhDone));
                 px3[2] += __popcll(__ballot(!alive));
-                if (can_step) bvh_node_step<R>(A.sc, q, A.tmin, stack, top, fetch_ticks);
+                if (can_step) bvh_node_step<R>(A.sc, q, tmin32, stack, fetch_ticks);
 #else
-                if (can_step) bvh_node_step<R>(A.sc, q, A.tmin, stack, top);
+                if (can_step) bvh_node_step<R>(A.sc, q, tmin32, stack);
 #endif
                 node_tests += 2u * (uint32_t)n_can;
             }
@@ -1532,9 +1495,12 @@ template <class R> __global__ __launch_bounds__(64) void kat_kernel(uint32_t op,
         BvhQuery<R> q;
         bvh_begin<R>(q, v3(6), v3(9), 1u);
         q.tbest = (R)a[13];
-        R t0;
-        const r4 lo = {(R)a[0], (R)a[1], (R)a[2], R(0)}, hi = {(R)a[3], (R)a[4], (R)a[5], R(0)};
-        r[0] = bvh_box_hit<R>(lo, hi, q, (R)a[12], t0) ? 1.0 : 0.0;
+        q.tb32 = round_up_f32(q.tbest);
+        float t0;
+        // the box as the device holds it: f32, rounded outward (host: bvh_build.hpp roundDown / roundUp)
+        const f4 lo = {__double2float_rd(a[0]), __double2float_rd(a[1]), __double2float_rd(a[2]), 0.0f};
+        const f4 hi = {__double2float_ru(a[3]), __double2float_ru(a[4]), __double2float_ru(a[5]), 0.0f};
+        r[0] = bvh_box_hit<R>(lo, hi, q, round_down_f32((R)a[12]), t0) ? 1.0 : 0.0;
         r[1] = (double)t0;
         break;
     }

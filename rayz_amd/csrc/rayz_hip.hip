@@ -96,7 +96,7 @@ template <class R> struct SceneBuffers {
     r4* mat = nullptr;
     r4* tex = nullptr;
     r4* tri = nullptr;
-    r4* bvh_nodes = nullptr; // BVH traversal only
+    f4* bvh_nodes = nullptr; // BVH traversal only (f32 boxes for both precisions: the box test only culls)
     r4* bvh_leaf = nullptr;
     uint32_t nt_pad = 0, bvh_leaf_stride = 2, bvh_n_inner = 0;
     uint32_t n_big_leaves = 0, big_desc[4] = {0, 0, 0, 0};
@@ -107,7 +107,8 @@ template <class R> struct SceneBuffers {
         (void)hipFree(tri);
         (void)hipFree(bvh_nodes);
         (void)hipFree(bvh_leaf);
-        tri = bvh_nodes = bvh_leaf = nullptr;
+        tri = bvh_leaf = nullptr;
+        bvh_nodes = nullptr;
         bvh_ready = false;
         (void)hipFree(stat);
         (void)hipFree(movy);
@@ -416,17 +417,18 @@ template <class R> int upload_bvh_body(RayzScene* s, SceneBuffers<R>& b) {
     }
     if (b.bvh_ready) return RAYZ_OK;
     b.bvh_leaf_stride = s->triangles.empty() ? 2u : 3u;
-    // one record per INNER node holding its two children's boxes (narrowed outward: never smaller than the f64
+    // one record per INNER node holding its two children's boxes (narrowed outward to f32: never smaller than the f64
     // box) + in lo.w where each child leads: an inner index, or kBvhLeafFlag | leaf descriptor
     // (first << 4 | type1 << 3 | type0 << 2 | count)
-    std::vector<r4> nodes, leaf;
+    std::vector<f4> nodes;
+    std::vector<r4> leaf;
     // inner nodes are numbered breadth-first for the first kBvhTopNodes (the top levels, which the kernel keeps in LDS),
     // the rest in pre-order
     std::vector<uint32_t> inner_index(t.nodes.size(), 0xffffffffu), inner_order;
     uint32_t n_inner = 0;
     {
         const char* e = std::getenv("RAYZ_BVH_TOP"); // measurement only: number of top-of-tree records kept in LDS
-        const uint32_t top_cap = e ? (uint32_t)std::atoi(e) : (sizeof(R) == 4 ? 256u : 128u);
+        const uint32_t top_cap = e ? (uint32_t)std::atoi(e) : 256u;
         std::vector<size_t> frontier;
         if (!t.nodes.empty() && t.nodes[0].count == 0) frontier.push_back(0);
         for (size_t head = 0; head < frontier.size() && n_inner < top_cap; ++head) {
@@ -452,11 +454,11 @@ template <class R> int upload_bvh_body(RayzScene* s, SceneBuffers<R>& b) {
     auto child = [&](size_t c) {
         const rayz_bvh::FlatNode& n = t.nodes[c];
         const bool is_leaf = n.count != 0;
-        nodes.push_back(r4{rayz_bvh::roundDown<R>(n.box.lo[0]), rayz_bvh::roundDown<R>(n.box.lo[1]),
-                           rayz_bvh::roundDown<R>(n.box.lo[2]),
-                           Bits<R>::from(is_leaf ? (kBvhLeafFlag | leaf_info(n)) : inner_index[c])});
-        nodes.push_back(r4{rayz_bvh::roundUp<R>(n.box.hi[0]), rayz_bvh::roundUp<R>(n.box.hi[1]),
-                           rayz_bvh::roundUp<R>(n.box.hi[2]), R(0)});
+        nodes.push_back(f4{rayz_bvh::roundDown<float>(n.box.lo[0]), rayz_bvh::roundDown<float>(n.box.lo[1]),
+                           rayz_bvh::roundDown<float>(n.box.lo[2]),
+                           Bits<float>::from(is_leaf ? (kBvhLeafFlag | leaf_info(n)) : inner_index[c])});
+        nodes.push_back(f4{rayz_bvh::roundUp<float>(n.box.hi[0]), rayz_bvh::roundUp<float>(n.box.hi[1]),
+                           rayz_bvh::roundUp<float>(n.box.hi[2]), 0.0f});
     };
     if (!t.nodes.empty() && t.nodes[0].count != 0) { // the whole pool fits one leaf: a root record whose two child
         child(0);                                     // slots both name it (the repeat cannot change the result)
@@ -468,7 +470,7 @@ template <class R> int upload_bvh_body(RayzScene* s, SceneBuffers<R>& b) {
             child(t.nodes[i + 1].skip);       // right child = where the left subtree ends
         }
     }
-    if (n_inner >= (1u << 25)) // the walk addresses a record by a 32-bit byte offset (index << 6 for f32, << 7 for f64)
+    if (n_inner >= (1u << 25)) // the walk addresses a record by a 32-bit byte offset (index << 6)
         return fail(RAYZ_ERR_BAD_ARG, "BVH of %u inner nodes exceeds the device layout (2^25)", n_inner);
     b.bvh_n_inner = t.nodes.empty() ? 0u : n_inner;
     for (uint32_t prim : slots) {
@@ -496,7 +498,8 @@ template <class R> int upload_bvh(RayzScene* s, SceneBuffers<R>& b) {
     if (rc != RAYZ_OK) { // drop the partly built BVH buffers (the scan streams stay valid)
         (void)hipFree(b.bvh_nodes);
         (void)hipFree(b.bvh_leaf);
-        b.bvh_nodes = b.bvh_leaf = nullptr;
+        b.bvh_nodes = nullptr;
+        b.bvh_leaf = nullptr;
         b.bvh_ready = false;
         if (!s->narrow.bvh_ready) {
             (void)hipFree(s->narrow.bvh_sph64);
@@ -766,7 +769,7 @@ int render_impl(RayzScene* s, const DeviceCtx& ctx, SceneBuffers<R>& b, const Ra
     // the BVH kernel's LDS stack holds one entry per tree level below the root (nearer child first: the stack never
     // holds more than one entry per level); sized from THIS tree, so a shallow tree does not cap the occupancy
     const size_t bvh_stack_bytes = use_bvh ? ((size_t)s->bvh_dev.depth + 2) * block * sizeof(uint32_t) : 0;
-    const size_t bvh_top_bytes = use_bvh ? (size_t)b.bvh_top * 4 * sizeof(r4) : 0; // the tree's top: first in LDS
+    const size_t bvh_top_bytes = use_bvh ? (size_t)b.bvh_top * 4 * sizeof(f4) : 0; // the tree's top: first in LDS
     const size_t bvh_lds = bvh_top_bytes + bvh_stack_bytes;
     A.bvh_top_words = (uint32_t)(bvh_top_bytes / sizeof(uint32_t));
     if (use_bvh) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, trace_kernel_bvh<R>, block, bvh_lds));
