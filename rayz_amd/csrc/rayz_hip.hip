@@ -1051,7 +1051,11 @@ int check_device_list(const int* devices, int n) {
     if (n < 1 || n > RAYZ_MAX_DEVICES) return fail(RAYZ_ERR_BAD_ARG, "n_devices %d out of range [1,%d]", n, RAYZ_MAX_DEVICES);
     for (int i = 0; i < n; ++i) {
         if (devices[i] < 0 || devices[i] >= RAYZ_MAX_DEVICES) return fail(RAYZ_ERR_BAD_ARG, "device %d out of range", devices[i]);
-        for (int j = 0; j < i; ++j)
+        // (RAYZ_MULTI_ALLOW_DUPLICATE_DEVICES=1, tests only: a one-GPU box then runs the N-way sharding, the peer-copy
+        //  gather and the un-interleave for real, every "device" being the same one)
+        const char* e = std::getenv("RAYZ_MULTI_ALLOW_DUPLICATE_DEVICES");
+        const bool dup_ok = e && e[0] == '1';
+        for (int j = 0; j < i && !dup_ok; ++j)
             if (devices[j] == devices[i]) return fail(RAYZ_ERR_BAD_ARG, "device %d is listed twice", devices[i]);
     }
     return RAYZ_OK;

@@ -1,8 +1,10 @@
 """Several GPUs behind ONE call (`rayz_hip_multi_*`, `rayz_hip_render_multi`): the single `tracer.render()` of the
 reference's caller (src/rayz.zig:26) driving every device of the node.  The GPU box has one MI355X, so what runs
-here is the degenerate n = 1 case through the complete machinery — per-device contexts, ncclCommInitAll +
-ncclGather (or peer copies), the un-interleave kernel — and it must be bit-identical to the single-device entry
-points; the row dealing itself is covered for 2..8 shards by test_gpu_parity / test_dist_cpu."""
+here is (a) the degenerate n = 1 case through the complete machinery — per-device contexts, ncclCommInitAll +
+ncclGather (or peer copies), the un-interleave kernel — and (b) n = 2, 3, 8 with every "device" being device 0
+(RAYZ_MULTI_ALLOW_DUPLICATE_DEVICES=1, peer-copy transport: RCCL refuses a device twice): the N-way row dealing, N scenes,
+the gather into N slots and the un-interleave run for real.  Both must be bit-identical to the single-device entry
+points."""
 import ctypes as C
 
 import numpy as np
@@ -39,6 +41,36 @@ def test_multi_n1_is_bit_identical_to_single_device(gpu, oracle, transport, tile
         assert_images_equal(got, want, f"multi n=1 transport {transport} tile_rows {tile_rows}")
         assert (st.primary_rays, st.segments, st.sphere_tests) == (wst.primary_rays, wst.segments, wst.sphere_tests)
         assert st.kernel_ms > 0
+    m.close()
+
+
+@pytest.mark.parametrize("n", [2, 3, 8])
+@pytest.mark.parametrize("tile_rows", [0, 5])
+def test_multi_n_way_on_one_device(gpu, oracle, monkeypatch, n, tile_rows):
+    """N shards through rayz_hip_multi_render on a one-GPU box: the same device listed N times (test-only switch)."""
+    t = _scene()
+    sd, cam, p = t.scene_desc(), t.camera_desc(), t.params()
+    want, wst = gpu.render_host(sd, cam, p)
+    with pytest.raises(capi.RayzHipError, match="listed twice"):
+        render.MultiScene(sd, [0] * n, capi.GATHER_PEER_COPY)
+    monkeypatch.setenv("RAYZ_MULTI_ALLOW_DUPLICATE_DEVICES", "1")
+    m = render.MultiScene(sd, [0] * n, capi.GATHER_PEER_COPY)
+    assert m.info()["n_devices"] == n
+    p.tile_rows = tile_rows
+    for _ in range(2):
+        got, st = m.render(cam, p)
+        assert_images_equal(got, want, f"multi n={n} (one device) tile_rows {tile_rows}")
+        assert (st.primary_rays, st.segments) == (wst.primary_rays, wst.segments)
+    u8, _ = m.render(cam, p, u8=True)
+    img = tracer.Image(p.height, p.width)
+    img.pixels = want.astype(np.float64)
+    assert np.array_equal(u8, img.to_u8())
+    t.set_gpu(precision=capi.PRECISION_F64, traversal=capi.TRAVERSAL_BVH)
+    p64 = t.params()
+    p64.tile_rows = tile_rows
+    got64, _ = m.render(cam, p64)
+    want64, _ = oracle.render_b(sd, cam, p64)
+    assert_images_equal(got64, want64, f"multi n={n} f64 BVH")
     m.close()
 
 
