@@ -628,6 +628,8 @@ template <class R> struct Sph {
     R r2;       // PADDED square of the conservative filter: (r + E)² rounded up, padRadius2()
     double radius;
     V<R> v;
+    V<float> cf, vf; // the FLAT-LIST scan's copy: f32 for both precisions (the reject test only filters, §4.3)
+    float r2f;       //   .. with its own padded square, padRadius2Scan()
     double c64[3], v64[3], r2_64; // narrow phase: the pool's own f64 values
     u32 mat;
     u32 pool; // index in MemPool.spheres
@@ -669,6 +671,14 @@ template <class R> static R padRadius2(const RayzSphere& q, double S) {
     const double rp = std::fabs(q.radius) + E;
     return roundUp<R>(rp * rp);
 }
+// The flat-list scan's filter runs in f32 for both precisions.  For R = double the ray reaches it narrowed to f32 (origin,
+// unit direction, time: ≤ u·S + u·(|c| + S) + u·|v| more on the line's distance to the centre): pad 40u instead of 32u.
+template <class R> static float padRadius2Scan(const RayzSphere& q, double S) {
+    const double u = (double)std::numeric_limits<float>::epsilon() / 2;
+    const double E = (sizeof(R) == 4 ? 32.0 : 40.0) * u * (norm3(q.center) + norm3(q.velocity) + std::fabs(q.radius) + S);
+    const double rp = std::fabs(q.radius) + E;
+    return roundUp<float>(rp * rp);
+}
 static double originBound(const RayzSceneDesc& d, const RayzCameraDesc* c) {
     double S = 0;
     for (u32 i = 0; i < d.n_spheres; ++i)
@@ -691,6 +701,9 @@ template <class R> static SceneB<R> buildScene(const RayzSceneDesc& d, double S)
             o.c = narrow3<R>(q.center);
             o.v = narrow3<R>(q.velocity);
             o.r2 = padRadius2<R>(q, S);
+            o.cf = narrow3<float>(q.center);
+            o.vf = narrow3<float>(q.velocity);
+            o.r2f = padRadius2Scan<R>(q, S);
             o.radius = q.radius;
             for (int k = 0; k < 3; ++k) o.c64[k] = q.center[k], o.v64[k] = q.velocity[k];
             o.r2_64 = q.radius * q.radius;
@@ -1100,21 +1113,27 @@ static PathResult<R> tracePath(const SceneB<R>& sc, const CamB<R>& cam, const Ra
         const V<R> ud = unit(d);
         R tbest = inf;
         int ibest = -1;
-        const Basis<R> basis = makeBasis<R>(ud, o);
+        const Basis<R> basis = makeBasis<R>(ud, o); // BVH leaves: the reject test in R
+        // flat list: the reject test in f32 for both precisions, on the ray narrowed to f32
+        const Basis<float> basisf = makeBasis<float>(V<float>{(float)ud.x, (float)ud.y, (float)ud.z},
+                                                     V<float>{(float)o.x, (float)o.y, (float)o.z});
+        const float timef = (float)time;
+        const bool flat = !useBvh(p, (u32)(sc.sph.size() + sc.tri.size()));
         auto testSphere = [&](const Sph<R>& q) {
-            const R disc = sphereFilter<R>(basis, time, q.c, q.v, q.r2);
+            const bool cand = flat ? sphereFilter<float>(basisf, timef, q.cf, q.vf, q.r2f) >= 0.0f
+                                   : sphereFilter<R>(basis, time, q.c, q.v, q.r2) >= R(0);
             if (audit) {
                 R tb = inf;
                 int ib = -1;
                 const double disc2 = narrowRoots<R>(q.c64, q.v64, q.r2_64, o, d, time, tmin, (int)q.pool, tb, ib);
-                const R plain = (R)q.radius * (R)q.radius; // what the filter used before it was made conservative
+                const float plain = (float)q.radius * (float)q.radius; // what the filter used before it was made conservative
                 audit->pairs++;
-                audit->candidates += disc >= R(0);
+                audit->candidates += cand;
                 audit->f64_hits += disc2 >= 0.0;
-                audit->false_negatives += disc2 >= 0.0 && !(disc >= R(0));
-                audit->unpadded_false_negatives += disc2 >= 0.0 && !(sphereFilter<R>(basis, time, q.c, q.v, plain) >= R(0));
+                audit->false_negatives += disc2 >= 0.0 && !cand;
+                audit->unpadded_false_negatives += disc2 >= 0.0 && !(sphereFilter<float>(basisf, timef, q.cf, q.vf, plain) >= 0.0f);
             }
-            if (!(disc >= R(0))) return;
+            if (!cand) return;
             narrowRoots<R>(q.c64, q.v64, q.r2_64, o, d, time, tmin, (int)q.pool, tbest, ibest);
         };
         const u32 n_sph = (u32)sc.sph.size();

@@ -58,9 +58,10 @@ template <> struct VecOf<double> { typedef d4 type; typedef d2 pair; };
 // in that order.  The f64 copies feed the narrow phase.
 template <class R> struct DevScene {
     typedef typename VecOf<R>::type r4;
-    const R* stat;           // [4 * ns_pad + spare block]
-    const R* movy;           // [5 * ny_pad + spare block]
-    const r4* movg;
+    const float* stat;       // [4 * ns_pad + spare block]   (the scan streams are f32 for both precisions: the reject test
+                             //                               only filters, the narrow phase decides — DESIGN.md §4.3)
+    const float* movy;       // [5 * ny_pad + spare block]
+    const f4* movg;
     const d4* slot64;        // [2 * slots] the pool's own f64 values per slot: {cx, cy, cz, r²}, {vx, vy, vz, 0}
     const uint32_t* slot_pool; // [slots] pool index of each slot
     const r4* sph_pool;      // [2 * n_spheres] by POOL index: {cx, cy, cz, r²}, {vx, vy, vz, bits(material)}
@@ -354,7 +355,7 @@ template <class R> struct ScanGroup<R, 0> { // static
     typedef typename VecOf<R>::pair pr;
     static constexpr int G = group_size<R>(), H = G / 2;
     pr cx[H], cy[H], cz[H], r2[H];
-    static __device__ __forceinline__ const RAYZ_CONSTANT R* stream(const DevScene<R>& sc) { return (const RAYZ_CONSTANT R*)sc.stat; }
+    template <class SC> static __device__ __forceinline__ const RAYZ_CONSTANT R* stream(const SC& sc) { return (const RAYZ_CONSTANT R*)sc.stat; }
     __device__ __forceinline__ void load(const RAYZ_CONSTANT R* base, int i) {
         const RAYZ_CONSTANT pr* p = (const RAYZ_CONSTANT pr*)(base + 4 * i);
 #pragma unroll
@@ -380,13 +381,13 @@ template <class R> struct ScanGroup<R, 0> { // static
             out[2 * q + 1] = d.y;
         }
     }
-    static __device__ __forceinline__ int slot0(const DevScene<R>&) { return 0; }
+    template <class SC> static __device__ __forceinline__ int slot0(const SC&) { return 0; }
 };
 template <class R> struct ScanGroup<R, 1> { // mov-Y
     typedef typename VecOf<R>::pair pr;
     static constexpr int G = group_size<R>(), H = G / 2;
     pr cx[H], cy[H], cz[H], r2[H], vy[H];
-    static __device__ __forceinline__ const RAYZ_CONSTANT R* stream(const DevScene<R>& sc) { return (const RAYZ_CONSTANT R*)sc.movy; }
+    template <class SC> static __device__ __forceinline__ const RAYZ_CONSTANT R* stream(const SC& sc) { return (const RAYZ_CONSTANT R*)sc.movy; }
     __device__ __forceinline__ void load(const RAYZ_CONSTANT R* base, int i) {
         const RAYZ_CONSTANT pr* p = (const RAYZ_CONSTANT pr*)(base + 5 * i);
 #pragma unroll
@@ -415,13 +416,13 @@ template <class R> struct ScanGroup<R, 1> { // mov-Y
             out[2 * q + 1] = d.y;
         }
     }
-    static __device__ __forceinline__ int slot0(const DevScene<R>& sc) { return (int)sc.ns_pad; }
+    template <class SC> static __device__ __forceinline__ int slot0(const SC& sc) { return (int)sc.ns_pad; }
 };
 template <class R> struct ScanGroup<R, 2> { // mov-G
     typedef typename VecOf<R>::type r4;
     static constexpr int G = kMovGGroup;
     r4 c[G], v[G];
-    static __device__ __forceinline__ const RAYZ_CONSTANT R* stream(const DevScene<R>& sc) { return (const RAYZ_CONSTANT R*)sc.movg; }
+    template <class SC> static __device__ __forceinline__ const RAYZ_CONSTANT R* stream(const SC& sc) { return (const RAYZ_CONSTANT R*)sc.movg; }
     __device__ __forceinline__ void load(const RAYZ_CONSTANT R* base, int i) {
         const RAYZ_CONSTANT r4* p = (const RAYZ_CONSTANT r4*)base + 2 * i;
 #pragma unroll
@@ -443,14 +444,15 @@ template <class R> struct ScanGroup<R, 2> { // mov-G
 #pragma unroll
         for (int k = 0; k < G; ++k) out[k] = disc(k, b, time);
     }
-    static __device__ __forceinline__ int slot0(const DevScene<R>& sc) { return (int)(sc.ns_pad + sc.ny_pad); }
+    template <class SC> static __device__ __forceinline__ int slot0(const SC& sc) { return (int)(sc.ns_pad + sc.ny_pad); }
 };
 
 // What the scan needs of one ray (one of the NR rays a lane carries).
 template <class R> struct ScanRay {
     V<R> o, d;
     R time;
-    RayBasis<R> basis;
+    RayBasis<float> basis; // the reject test runs in f32 for both precisions (FilterR): built from ud, o narrowed to f32
+    float ftime;
     double inv_a2; // 1 / (d·d) in f64, for the narrow phase
     R tbest;
     int ibest;
@@ -460,12 +462,12 @@ template <class R> struct ScanRay {
 
 // Reject tests of one group for the lane's NR rays; the running maximum feeds the pair's single branch.
 template <class R, int CLS, int NR>
-__device__ __forceinline__ void group_discs(const ScanGroup<R, CLS>& g, ScanRay<R> (&ray)[NR], R (&disc)[NR][ScanGroup<R, CLS>::G],
-                                            R& m, bool first) {
-    constexpr int G = ScanGroup<R, CLS>::G;
+__device__ __forceinline__ void group_discs(const ScanGroup<float, CLS>& g, ScanRay<R> (&ray)[NR],
+                                            float (&disc)[NR][ScanGroup<float, CLS>::G], float& m, bool first) {
+    constexpr int G = ScanGroup<float, CLS>::G;
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
-        g.discs(disc[r], ray[r].basis, ray[r].time);
+        g.discs(disc[r], ray[r].basis, ray[r].ftime);
 #pragma unroll
         for (int k = 0; k < G; ++k) m = (first && r == 0 && k == 0) ? disc[0][0] : mx(m, disc[r][k]);
     }
@@ -489,13 +491,13 @@ template <class R, int NR> __device__ __forceinline__ void narrow_flush(const De
 // Park one group's candidates (slots first .. first+G-1); a lane whose list is full forces a flush first.
 template <class R, int CLS, int NR>
 __device__ __forceinline__ void group_collect(const DevScene<R>& sc, int first, ScanRay<R> (&ray)[NR],
-                                              const R (&disc)[NR][ScanGroup<R, CLS>::G], R tmin) {
-    constexpr int G = ScanGroup<R, CLS>::G;
+                                              const float (&disc)[NR][ScanGroup<float, CLS>::G], R tmin) {
+    constexpr int G = ScanGroup<float, CLS>::G;
 #pragma unroll
     for (int k = 0; k < G; ++k)
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-            const bool want = disc[r][k] >= R(0);
+            const bool want = disc[r][k] >= 0.0f;
             // usually ONE of the group's spheres made the wave take this path: the others cost a compare and a scalar
             // branch instead of the whole insertion (a small scene takes this path in almost every group: measured +2.5 %
             // on config 2; parking whole group pairs in LDS and re-testing them per lane afterwards was 13 % SLOWER)
@@ -519,18 +521,18 @@ __device__ __forceinline__ void group_collect(const DevScene<R>& sc, int first, 
 // keep hipcc from sinking the loads.  The branch costs ≈10 cycles of a wave's time: once per 8 tests, not 4.)
 template <class R, int CLS, int NR>
 __device__ __forceinline__ void scan_class(const DevScene<R>& sc, int n, ScanRay<R> (&ray)[NR], R tmin) {
-    constexpr int G = ScanGroup<R, CLS>::G;
+    constexpr int G = ScanGroup<float, CLS>::G;
     if (n == 0) return;
     // the stream's base as a value of its own: read out of the kernel arguments it is one lane of a 16-register block,
     // and a spilled block comes back whole (the f64 kernel paid 20 v_readlane per iteration for this one pointer)
-    const RAYZ_CONSTANT R* base = ScanGroup<R, CLS>::stream(sc);
+    const RAYZ_CONSTANT float* base = ScanGroup<float, CLS>::stream(sc);
     if constexpr (sizeof(R) == 8) asm volatile("" : "+s"(base));
-    ScanGroup<R, CLS> a, b;
+    ScanGroup<float, CLS> a, b;
     a.load(base, 0);
     b.load(base, G);
     for (int i = 0; i < n; i += 2 * G) {
-        R da[NR][G], db[NR][G];
-        R m = R(-1);
+        float da[NR][G], db[NR][G];
+        float m = -1.0f;
 #ifdef RAYZ_DEBUG_NOFEED // timing experiment only: never reload (wrong results); values kept opaque to the compiler
         a.opaque();
         group_discs<R, CLS, NR>(a, ray, da, m, true);
@@ -546,11 +548,11 @@ __device__ __forceinline__ void scan_class(const DevScene<R>& sc, int n, ScanRay
         __builtin_amdgcn_sched_barrier(0);
 #endif
 #ifdef RAYZ_DEBUG_NONARROW // timing experiment only (wrong results)
-        if (m >= R(1e30)) {
+        if (m >= 1e30f) {
 #else
-        if (m >= R(0)) { // any lane, any ray, any of the 2·G spheres: rare
+        if (m >= 0.0f) { // any lane, any ray, any of the 2·G spheres: rare
 #endif
-            const int slot0 = ScanGroup<R, CLS>::slot0(sc);
+            const int slot0 = ScanGroup<float, CLS>::slot0(sc);
             group_collect<R, CLS, NR>(sc, slot0 + i, ray, da, tmin);
             group_collect<R, CLS, NR>(sc, slot0 + i + G, ray, db, tmin);
         }
@@ -623,7 +625,8 @@ __device__ __forceinline__ void scan_begin(ScanRay<R>& ray, V<R> o, V<R> d, V<R>
     ray.o = o;
     ray.d = d;
     ray.time = time;
-    ray.basis = make_basis<R>(ud, o);
+    ray.basis = make_basis<float>(V<float>{(float)ud.x, (float)ud.y, (float)ud.z}, V<float>{(float)o.x, (float)o.y, (float)o.z});
+    ray.ftime = (float)time;
     const double ddx = d.x, ddy = d.y, ddz = d.z;
     ray.inv_a2 = 1.0 / fm(ddz, ddz, fm(ddy, ddy, ddx * ddx));
     ray.tbest = (R)__builtin_inff();

@@ -89,9 +89,9 @@ struct DeviceScope {
 // Device copy of the scene in one precision: scan streams + pool-indexed shading tables.
 template <class R> struct SceneBuffers {
     typedef typename VecOf<R>::type r4;
-    R* stat = nullptr;  // blocks of G = group_size<R>() spheres: cx[G] cy[G] cz[G] r²[G]
-    R* movy = nullptr;  // blocks of G: cx[G] cy[G] cz[G] r²[G] vy[G]
-    r4* movg = nullptr;
+    float* stat = nullptr;  // blocks of G = 4 spheres: cx[G] cy[G] cz[G] r²[G]   (scan streams: f32 for both precisions)
+    float* movy = nullptr;  // blocks of G: cx[G] cy[G] cz[G] r²[G] vy[G]
+    f4* movg = nullptr;
     r4* sph_pool = nullptr;
     r4* mat = nullptr;
     r4* tex = nullptr;
@@ -116,7 +116,8 @@ template <class R> struct SceneBuffers {
         (void)hipFree(sph_pool);
         (void)hipFree(mat);
         (void)hipFree(tex);
-        movg = sph_pool = mat = tex = nullptr;
+        sph_pool = mat = tex = nullptr;
+        movg = nullptr;
         stat = movy = nullptr;
         ready = false;
     }
@@ -185,6 +186,14 @@ double norm3(const double* v) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2
 // hittable).  The padded square is rounded UP to R.  Candidates are decided by the f64 narrow phase, so the padding
 // changes no image — it only guarantees that no sphere with an f64 discriminant ≥ 0 is filtered out.
 template <class R> constexpr double unit_roundoff() { return sizeof(R) == 4 ? 5.9604644775390625e-08 : 1.1102230246251565e-16; }
+// The scan streams' filter runs in f32 for both precisions.  For R = double the ray reaches it narrowed to f32 (origin,
+// unit direction, time: ≤ u·S + u·(|c| + S) + u·|v| more on the line's distance to the centre), so its pad is 40u, not 32u.
+template <class R> float pad_radius2_scan(const RayzSphere& q, double S) {
+    const double E = (sizeof(R) == 4 ? 32.0 : 40.0) * unit_roundoff<float>() *
+                     (norm3(q.center) + norm3(q.velocity) + std::fabs(q.radius) + S);
+    const double rp = std::fabs(q.radius) + E;
+    return rayz_bvh::roundUp<float>(rp * rp);
+}
 template <class R> R pad_radius2(const RayzSphere& q, double S) {
     const double E = 32.0 * unit_roundoff<R>() * (norm3(q.center) + norm3(q.velocity) + std::fabs(q.radius) + S);
     const double rp = std::fabs(q.radius) + E;
@@ -292,35 +301,38 @@ template <class R> int upload_body(RayzScene* s, SceneBuffers<R>& b) {
     typedef typename VecOf<R>::type r4;
     int rc = upload_narrow(s);
     if (rc != RAYZ_OK) return rc;
-    const R ninf = -std::numeric_limits<R>::infinity();
-    const r4 pad = {R(0), R(0), R(0), ninf}; // r² = -inf: the discriminant is -inf (or NaN), never ≥ 0
     auto rec = [&](uint32_t pool) { // w = the PADDED r² of the conservative filter
         const RayzSphere& q = s->spheres[pool];
         return r4{(R)q.center[0], (R)q.center[1], (R)q.center[2], pad_radius2<R>(q, b.pad_S)};
     };
-    // static / mov-Y streams: blocks of G spheres, SoA inside a block (field f of sphere k of block g at
-    // g·F·G + f·G + k), pad spheres {0, 0, 0, r² = -inf, vy = 0}
+    // static / mov-Y streams (f32 for both precisions): blocks of G spheres, SoA inside a block (field f of sphere k of
+    // block g at g·F·G + f·G + k), pad spheres {0, 0, 0, r² = -inf, vy = 0}
+    const float ninf32 = -std::numeric_limits<float>::infinity();
+    auto rec32 = [&](uint32_t pool) { // w = the PADDED r² of the conservative filter
+        const RayzSphere& q = s->spheres[pool];
+        return f4{(float)q.center[0], (float)q.center[1], (float)q.center[2], pad_radius2_scan<R>(q, b.pad_S)};
+    };
     auto blocks = [&](const std::vector<uint32_t>& cls, uint32_t G, uint32_t F, uint32_t scanned) {
-        const uint32_t n = scanned + 2 * G; // the scanned slots (shared by both precisions) + two spare groups
-        std::vector<R> v((size_t)n * F, R(0));
-        for (uint32_t k = 0; k < n; ++k) v[(size_t)(k / G) * F * G + 3 * G + k % G] = ninf;
+        const uint32_t n = scanned + 2 * G; // the scanned slots + two spare groups
+        std::vector<float> v((size_t)n * F, 0.0f);
+        for (uint32_t k = 0; k < n; ++k) v[(size_t)(k / G) * F * G + 3 * G + k % G] = ninf32;
         for (size_t k = 0; k < cls.size(); ++k) {
             const RayzSphere& q = s->spheres[cls[k]];
-            const r4 c = rec(cls[k]);
-            R* blk = v.data() + (k / G) * F * G + k % G;
+            const f4 c = rec32(cls[k]);
+            float* blk = v.data() + (k / G) * F * G + k % G;
             blk[0] = c.x, blk[G] = c.y, blk[2 * G] = c.z, blk[3 * G] = c.w;
-            if (F == 5) blk[4 * G] = (R)q.velocity[1];
+            if (F == 5) blk[4 * G] = (float)q.velocity[1];
         }
         return v;
     };
-    const std::vector<R> stat = blocks(s->cls[0], group_size<R>(), 4, s->narrow.ns_pad),
-                         movy = blocks(s->cls[1], group_size<R>(), 5, s->narrow.ny_pad);
-    std::vector<r4> movg(2 * (size_t)stream_len(s->cls[2].size(), kMovGGroup), r4{R(0), R(0), R(0), R(0)});
-    for (size_t k = 0; k < movg.size(); k += 2) movg[k] = pad;
+    const std::vector<float> stat = blocks(s->cls[0], group_size<float>(), 4, s->narrow.ns_pad),
+                             movy = blocks(s->cls[1], group_size<float>(), 5, s->narrow.ny_pad);
+    std::vector<f4> movg(2 * (size_t)stream_len(s->cls[2].size(), kMovGGroup), f4{0.0f, 0.0f, 0.0f, 0.0f});
+    for (size_t k = 0; k < movg.size(); k += 2) movg[k] = f4{0.0f, 0.0f, 0.0f, ninf32};
     for (size_t k = 0; k < s->cls[2].size(); ++k) {
         const RayzSphere& q = s->spheres[s->cls[2][k]];
-        movg[2 * k] = rec(s->cls[2][k]);
-        movg[2 * k + 1] = r4{(R)q.velocity[0], (R)q.velocity[1], (R)q.velocity[2], R(0)};
+        movg[2 * k] = rec32(s->cls[2][k]);
+        movg[2 * k + 1] = f4{(float)q.velocity[0], (float)q.velocity[1], (float)q.velocity[2], 0.0f};
     }
     // triangles: {v0, bits(material)}, {e1, 0}, {e2, 0}; edges subtracted in f64, then narrowed
     b.nt_pad = scan_len(s->triangles.size(), kTriGroup);

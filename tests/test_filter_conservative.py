@@ -20,8 +20,12 @@ def test_no_false_negatives_over_config3_segments(oracle):
     assert au["false_negatives"] == 0
     assert au["f64_hits"] <= au["candidates"] <= 1.25 * au["f64_hits"] + 1000  # the padding lets few extra pairs through
     print("filter audit f32:", au)
-    au64 = oracle.filter_audit(sd, cam, p, pixels[:1500], capi.PRECISION_F64)
-    assert au64["false_negatives"] == 0 and au64["pairs"] > 5e7
+    # f64 fidelity mode: the flat list's reject test is the SAME f32 test, on the f64 ray narrowed to f32 (pad 40u): it
+    # must let through every pair the f64 quadratic of the f64 ray hits
+    au64 = oracle.filter_audit(sd, cam, p, pixels, capi.PRECISION_F64)
+    assert au64["false_negatives"] == 0 and au64["pairs"] > 2.5e8
+    assert au64["f64_hits"] <= au64["candidates"] <= 1.25 * au64["f64_hits"] + 1000
+    print("filter audit f64 rays through the f32 filter:", au64)
 
 
 def test_no_false_negatives_on_grazing_rays_and_big_coordinates(oracle):
