@@ -625,11 +625,10 @@ template <class R> struct Mat {
 };
 template <class R> struct Sph {
     V<R> c;     // broad phase, narrowed to R
-    R r2;       // PADDED square of the conservative filter: (r + E)² rounded up, padRadius2()
     double radius;
     V<R> v;
-    V<float> cf, vf; // the FLAT-LIST scan's copy: f32 for both precisions (the reject test only filters, §4.3)
-    float r2f;       //   .. with its own padded square, padRadius2Scan()
+    V<float> cf, vf; // the reject test's copy: f32 for both precisions (the test only filters, §4.3)
+    float r2f;       //   .. the PADDED square of the conservative filter: (r + E)² rounded up, padRadius2Scan()
     double c64[3], v64[3], r2_64; // narrow phase: the pool's own f64 values
     u32 mat;
     u32 pool; // index in MemPool.spheres
@@ -663,15 +662,9 @@ template <class R> static V<R> narrow3(const double* p) { return {(R)p[0], (R)p[
 
 template <class R> static R roundUp(double v);
 static double norm3(const double* v) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
-// Conservative reject filter: r_pad = r + E, E = 32·u·(|c| + |v| + r + S); u = unit roundoff of R,
+// Conservative reject filter: r_pad = r + E, E = 32·u·(|c| + |v| + r + S); u = unit roundoff of f32,
 // S = a bound on |o| of every ray.  Restated here, not shared with the product.
-template <class R> static R padRadius2(const RayzSphere& q, double S) {
-    const double u = (double)std::numeric_limits<R>::epsilon() / 2;
-    const double E = 32.0 * u * (norm3(q.center) + norm3(q.velocity) + std::fabs(q.radius) + S);
-    const double rp = std::fabs(q.radius) + E;
-    return roundUp<R>(rp * rp);
-}
-// The flat-list scan's filter runs in f32 for both precisions.  For R = double the ray reaches it narrowed to f32 (origin,
+// The filter runs in f32 for both precisions.  For R = double the ray reaches it narrowed to f32 (origin,
 // unit direction, time: ≤ u·S + u·(|c| + S) + u·|v| more on the line's distance to the centre): pad 40u instead of 32u.
 template <class R> static float padRadius2Scan(const RayzSphere& q, double S) {
     const double u = (double)std::numeric_limits<float>::epsilon() / 2;
@@ -700,7 +693,6 @@ template <class R> static SceneB<R> buildScene(const RayzSceneDesc& d, double S)
             Sph<R> o;
             o.c = narrow3<R>(q.center);
             o.v = narrow3<R>(q.velocity);
-            o.r2 = padRadius2<R>(q, S);
             o.cf = narrow3<float>(q.center);
             o.vf = narrow3<float>(q.velocity);
             o.r2f = padRadius2Scan<R>(q, S);
@@ -1113,15 +1105,12 @@ static PathResult<R> tracePath(const SceneB<R>& sc, const CamB<R>& cam, const Ra
         const V<R> ud = unit(d);
         R tbest = inf;
         int ibest = -1;
-        const Basis<R> basis = makeBasis<R>(ud, o); // BVH leaves: the reject test in R
-        // flat list: the reject test in f32 for both precisions, on the ray narrowed to f32
+        // the reject test: in f32 for both precisions, on the ray narrowed to f32 (flat-list scan and BVH leaves alike)
         const Basis<float> basisf = makeBasis<float>(V<float>{(float)ud.x, (float)ud.y, (float)ud.z},
                                                      V<float>{(float)o.x, (float)o.y, (float)o.z});
         const float timef = (float)time;
-        const bool flat = !useBvh(p, (u32)(sc.sph.size() + sc.tri.size()));
         auto testSphere = [&](const Sph<R>& q) {
-            const bool cand = flat ? sphereFilter<float>(basisf, timef, q.cf, q.vf, q.r2f) >= 0.0f
-                                   : sphereFilter<R>(basis, time, q.c, q.v, q.r2) >= R(0);
+            const bool cand = sphereFilter<float>(basisf, timef, q.cf, q.vf, q.r2f) >= 0.0f;
             if (audit) {
                 R tb = inf;
                 int ib = -1;
@@ -1392,8 +1381,10 @@ template <class R> static void katB(uint32_t op, const double* a, double* r) {
         const R time = (R)a[13], tmin = (R)a[14];
         const double S = std::max(norm3(a + 7), norm3(q.center) + norm3(q.velocity) + std::fabs(q.radius));
         const V<R> c = v3(0), v = v3(3);
-        const Basis<R> b = makeBasis<R>(unit(d), o);
-        const bool cand = sphereFilter<R>(b, time, c, v, padRadius2<R>(q, S)) >= R(0);
+        const V<R> udk = unit(d); // the reject test as the kernels run it: f32 for both precisions, the ray narrowed to f32
+        const Basis<float> b = makeBasis<float>(V<float>{(float)udk.x, (float)udk.y, (float)udk.z}, V<float>{(float)o.x, (float)o.y, (float)o.z});
+        const bool cand = sphereFilter<float>(b, (float)time, V<float>{(float)c.x, (float)c.y, (float)c.z},
+                                              V<float>{(float)v.x, (float)v.y, (float)v.z}, padRadius2Scan<R>(q, S)) >= 0.0f;
         r[9] = cand ? 1.0 : 0.0;
         R tbest = (R)a[15];
         int ibest = -1;

@@ -1173,10 +1173,13 @@ __device__ __forceinline__ uint32_t bvh_leaf_entry(const DevScene<R>& sc, BvhQue
         tri_accept<R>(tri_filter<R>(v0, e1, ee2, o, d), v0, e1, ee2, o, d, tmin, (int)bits(c.w), q.tbest, q.ibest);
         return 0u;
     }
-    const RayBasis<R> b = make_basis<R>(ud, o); // same filter as the flat list (hipcc shares it between both entries)
-    const R p1 = fm(v.z, time * b.e1z, fm(v.x, time * b.e1x, basis_p1<R>(b, c.x, c.z)));
-    const R p2 = fm(v.z, time * b.e2z, fm(v.y, time * b.e2y, fm(v.x, time * b.e2x, basis_p2<R>(b, c.x, c.y, c.z))));
-    return sphere_candidate<R>(p1, p2, c.w) ? slot + 1u : 0u;
+    // the flat list's reject test: in f32 for both precisions, on the ray narrowed to f32 (hipcc shares the basis between
+    // both entries of a leaf); c.w = the f32 padded square
+    const RayBasis<float> b = make_basis<float>(V<float>{(float)ud.x, (float)ud.y, (float)ud.z}, V<float>{(float)o.x, (float)o.y, (float)o.z});
+    const float ft = (float)time, vx = (float)v.x, vy = (float)v.y, vz = (float)v.z;
+    const float p1 = fm(vz, ft * b.e1z, fm(vx, ft * b.e1x, basis_p1<float>(b, (float)c.x, (float)c.z)));
+    const float p2 = fm(vz, ft * b.e2z, fm(vy, ft * b.e2y, fm(vx, ft * b.e2x, basis_p2<float>(b, (float)c.x, (float)c.y, (float)c.z))));
+    return sphere_candidate<float>(p1, p2, (float)c.w) ? slot + 1u : 0u;
 }
 
 // Phase C — the f64 quadratic of a parked sphere candidate (same arithmetic as narrow_phase()).
@@ -1224,8 +1227,8 @@ constexpr int kBvhKeepStepping = 16; // phase N continues while at least this ma
 #ifndef RAYZ_BVH_WAVES
 #define RAYZ_BVH_WAVES 4
 #endif
-#ifndef RAYZ_BVH_WAVES_F64
-#define RAYZ_BVH_WAVES_F64 3
+#ifndef RAYZ_BVH_WAVES_F64 // the f64 kernel fits 128 VGPRs too since its box walk and its reject tests run in f32 (it needed
+#define RAYZ_BVH_WAVES_F64 4 // 151 and ran 3 waves per SIMD before: +13 % from the fourth)
 #endif
 template <class R> constexpr int bvh_waves() { return sizeof(R) == 8 ? RAYZ_BVH_WAVES_F64 : RAYZ_BVH_WAVES; }
 template <class R> __global__ __launch_bounds__(256, bvh_waves<R>()) void trace_kernel_bvh(const TraceArgs<R> A) {
@@ -1510,12 +1513,14 @@ template <class R> __global__ __launch_bounds__(64) void kat_kernel(uint32_t op,
     case 4: { // SPHERE_HIT: c(3) v(3) radius o(3) d(3) time tmin tmax -> hit t point(3) normal(3) front filter
         const V<R> o = v3(7), d = v3(10);
         const R time = (R)a[13], tmin = (R)a[14];
-        const r4 c = {(R)a[0], (R)a[1], (R)a[2], (R)a[16]}, v = {(R)a[3], (R)a[4], (R)a[5], R(0)}; // a[16]: padded r², from the host
+        const r4 c = {(R)a[0], (R)a[1], (R)a[2], (R)a[16]}, v = {(R)a[3], (R)a[4], (R)a[5], R(0)}; // a[16]: padded r² (f32), from the host
         const V<R> ud = unit(d);
-        const RayBasis<R> b = make_basis<R>(ud, o);
-        const R p1 = fm(v.z, time * b.e1z, fm(v.x, time * b.e1x, basis_p1<R>(b, c.x, c.z)));
-        const R p2 = fm(v.z, time * b.e2z, fm(v.y, time * b.e2y, fm(v.x, time * b.e2x, basis_p2<R>(b, c.x, c.y, c.z))));
-        const bool cand = sphere_candidate<R>(p1, p2, c.w);
+        // the reject test as the kernels run it: f32 for both precisions, the ray narrowed to f32
+        const RayBasis<float> b = make_basis<float>(V<float>{(float)ud.x, (float)ud.y, (float)ud.z}, V<float>{(float)o.x, (float)o.y, (float)o.z});
+        const float ft = (float)time, vx = (float)v.x, vy = (float)v.y, vz = (float)v.z;
+        const float p1 = fm(vz, ft * b.e1z, fm(vx, ft * b.e1x, basis_p1<float>(b, (float)c.x, (float)c.z)));
+        const float p2 = fm(vz, ft * b.e2z, fm(vy, ft * b.e2y, fm(vx, ft * b.e2x, basis_p2<float>(b, (float)c.x, (float)c.y, (float)c.z))));
+        const bool cand = sphere_candidate<float>(p1, p2, (float)c.w);
         r[9] = cand ? 1.0 : 0.0;
         R tbest = (R)a[15];
         int ibest = -1;

@@ -194,11 +194,6 @@ template <class R> float pad_radius2_scan(const RayzSphere& q, double S) {
     const double rp = std::fabs(q.radius) + E;
     return rayz_bvh::roundUp<float>(rp * rp);
 }
-template <class R> R pad_radius2(const RayzSphere& q, double S) {
-    const double E = 32.0 * unit_roundoff<R>() * (norm3(q.center) + norm3(q.velocity) + std::fabs(q.radius) + S);
-    const double rp = std::fabs(q.radius) + E;
-    return rayz_bvh::roundUp<R>(rp * rp);
-}
 double scene_origin_bound(const RayzScene* s);
 double camera_origin_bound(const RayzCameraDesc* c) { return norm3(c->look_from) + norm3(c->defocus_u) + norm3(c->defocus_v); }
 
@@ -303,7 +298,7 @@ template <class R> int upload_body(RayzScene* s, SceneBuffers<R>& b) {
     if (rc != RAYZ_OK) return rc;
     auto rec = [&](uint32_t pool) { // w = the PADDED r² of the conservative filter
         const RayzSphere& q = s->spheres[pool];
-        return r4{(R)q.center[0], (R)q.center[1], (R)q.center[2], pad_radius2<R>(q, b.pad_S)};
+        return r4{(R)q.center[0], (R)q.center[1], (R)q.center[2], (R)pad_radius2_scan<R>(q, b.pad_S)};
     };
     // static / mov-Y streams (f32 for both precisions): blocks of G spheres, SoA inside a block (field f of sphere k of
     // block g at g·F·G + f·G + k), pad spheres {0, 0, 0, r² = -inf, vy = 0}
@@ -488,7 +483,7 @@ template <class R> int upload_bvh_body(RayzScene* s, SceneBuffers<R>& b) {
     for (uint32_t prim : slots) {
         if (prim < ns) {
             const RayzSphere& q = s->spheres[prim];
-            leaf.push_back(r4{(R)q.center[0], (R)q.center[1], (R)q.center[2], pad_radius2<R>(q, b.pad_S)});
+            leaf.push_back(r4{(R)q.center[0], (R)q.center[1], (R)q.center[2], (R)pad_radius2_scan<R>(q, b.pad_S)});
             leaf.push_back(r4{(R)q.velocity[0], (R)q.velocity[1], (R)q.velocity[2], Bits<R>::from(prim)});
             if (b.bvh_leaf_stride == 3) leaf.push_back(r4{R(0), R(0), R(0), R(0)});
         } else {
@@ -1368,7 +1363,7 @@ int rayz_hip_kat(uint32_t op, uint32_t precision, const double* in, uint32_t n, 
                 for (int k = 0; k < 3; ++k) q.center[k] = a[k], q.velocity[k] = a[3 + k];
                 q.radius = a[6];
                 const double S = std::max(norm3(a + 7), norm3(q.center) + norm3(q.velocity) + std::fabs(q.radius));
-                a[16] = precision == RAYZ_PRECISION_F32 ? (double)pad_radius2<float>(q, S) : pad_radius2<double>(q, S);
+                a[16] = precision == RAYZ_PRECISION_F32 ? (double)pad_radius2_scan<float>(q, S) : (double)pad_radius2_scan<double>(q, S);
             }
         }
         DeviceScope scope(device);
