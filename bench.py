@@ -28,7 +28,7 @@ PEAK_VALU_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 FLOP/c
 # FP64 vector peak: half the FP32 figure (64-bit FMA issues every 4 cycles per wave and SIMD).  Not in the local guide;
 # measured with tools/ubench/valu_peak.hip on the whole chip (profiles/r02/valu_peak.jsonl): v_fma_f64 75.1 TFLOP/s,
 # v_pk_fma_f32 140.2, v_fma_f32 121.7 under the clock the chip holds (95.5 % / 89 % / 77 % of the nominal figures).
-PEAK_VALU_F64_TFLOPS = 78.6
+PEAK_VALU_F64_TFLOPS = 78.6  # (measured 75.1, tools/ubench/valu_peak; no kernel is priced against it since the filters went f32)
 PEAK_HBM_GBPS = 8000.0
 FLOP_PER_BOX_TEST = 24        # trace_kernel_bvh: 6 fma + 6 min/max + two 3-input min/max + the slack fma
 FLOP_PER_TEST_MOVING = 24     # centre-at-time 6 + offset 3 + half_b 5 + c 7 + disc 3
@@ -287,7 +287,9 @@ def run(args, json_fd):
             if name == "bvh_traversal":
                 frames[name] = buf.cpu().numpy()
             bvh = traversal == capi.TRAVERSAL_BVH
-            peak_e = PEAK_VALU_F64_TFLOPS if precision == capi.PRECISION_F64 else PEAK_VALU_F32_TFLOPS
+            # the box walk and the reject tests run in f32 in BOTH precisions (they only filter; the f64
+            # quadratic of the f64 ray decides), so the dominant arithmetic of every one of these kernels is FP32
+            peak_e = PEAK_VALU_F32_TFLOPS
             if bvh:
                 fl = st.node_tests * FLOP_PER_BOX_TEST + st.sphere_tests * FLOP_PER_TEST_MOVING
             else:
@@ -295,14 +297,14 @@ def run(args, json_fd):
             ach = fl / (st.kernel_ms * 1e-3) / 1e12
             also[name] = {"value": H * W * spp / dt / 1e6, "unit": "Msamples/s", "spp": spp, "ms_per_step": dt * 1e3,
                           "kernel_ms": st.kernel_ms, "segments_per_sample": st.segments / st.primary_rays,
-                          "roofline": {"bound": "valu_fp64" if precision == capi.PRECISION_F64 else "valu_fp32",
+                          "roofline": {"bound": "valu_fp32",
                                        "achieved": ach, "peak": peak_e, "unit": "TFLOP/s", "frac": ach / peak_e,
                                        "kernel": ("trace_kernel_bvh" if bvh else "trace_kernel") +
                                                  ("<double>" if precision == capi.PRECISION_F64 else "<float>")}}
             if bvh:
                 also[name]["node_tests_per_segment"] = st.node_tests / max(st.segments, 1)
                 also[name]["sphere_tests_per_segment"] = st.sphere_tests / max(st.segments, 1)
-                also[name]["roofline"]["note"] = (f"per-lane tree walk, issue-bound at 36 of 64 lanes (profiles/r02): priced against the vector "
+                also[name]["roofline"]["note"] = (f"per-lane tree walk, issue-bound at 31 of 64 lanes (profiles/r02): priced against the vector "
                                                   f"peak with {FLOP_PER_BOX_TEST} flop per box test + {FLOP_PER_TEST_MOVING} per leaf test")
 
         sd0 = scene
@@ -366,7 +368,7 @@ def run(args, json_fd):
             note = ("per-lane tree walk: vector-ALU issue-bound at ~60 % lane use (SQ_ACTIVE_INST_VALU = 90 % of the SIMD "
                     "cycles, profiles/r02/pmc_summary.json), priced against the same FP32 vector peak; "
                     f"algorithmic flops = {FLOP_PER_BOX_TEST} x box tests + 24 x leaf sphere tests")
-        peak = PEAK_VALU_F64_TFLOPS if args.precision == "f64" else PEAK_VALU_F32_TFLOPS
+        peak = PEAK_VALU_F32_TFLOPS  # reject tests and box walk are f32 arithmetic in both precisions
         reference_achieved = flops / (kernel_ms_avg * 1e-3) / 1e12   # SURVEY 8d accounting
         achieved = executed_flops / (kernel_ms_avg * 1e-3) / 1e12    # what the kernel executes
         # HBM bytes per launch (FETCH_SIZE doubled — gfx950 wide-read correction, MI355X_MICROARCH.md — plus WRITE_SIZE)
@@ -401,10 +403,11 @@ def run(args, json_fd):
                 "collective_backend": backend, "collective_world_size": world if world > 1 else None,
                 "segments_per_sample": frame_segments / samples_per_step,
                 "arithmetic": ("f32 path state and reject test, f64 candidate roots (DESIGN.md 4.3), tmin 1e-3"
-                               if args.precision == "f32" else "f64 throughout, tmin 1e-10 (the reference's scalar type)"),
+                               if args.precision == "f32" else "f64 path state, roots, hit records and shading (the reference's scalar type), tmin 1e-10; "
+                               "the reject tests and the box walk — which only filter — in f32 (DESIGN.md 4.3 / 4.8)"),
             },
             "roofline": {
-                "bound": "valu_fp32" if args.precision == "f32" else "valu_fp64", "achieved": achieved, "peak": peak,
+                "bound": "valu_fp32", "achieved": achieved, "peak": peak,
                 "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                 "kernel": kernel, "kernel_ms": kernel_ms_avg, "note": note,
                 "reference_formulation": {"achieved": reference_achieved, "frac": reference_achieved / peak,
