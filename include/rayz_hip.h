@@ -232,7 +232,9 @@ int rayz_hip_render_f64(const RayzSceneDesc* scene, const RayzCameraDesc* camera
  * devices[0] over xGMI (ncclCommInitAll + ncclGather), or peer copies — reassembles the frame, which is copied
  * to the caller's HOST buffer (height*width*3, row-major RGB).  The image is bit-identical for any device count
  * (the per-(pixel,sample) streams are keyed by global pixel coordinates).  `params->shard_index/shard_count`
- * must be 0: the library shards.  Blocking; driven by the calling thread; one call at a time per handle. */
+ * must be 0: the library shards.  Blocking; driven by the calling thread; one call at a time per handle.
+ * A device may be listed once (RAYZ_ERR_BAD_ARG otherwise; the environment variable
+ * RAYZ_MULTI_ALLOW_DUPLICATE_DEVICES=1 lifts that for TESTS on a one-GPU box, peer-copy transport only). */
 typedef enum RayzGatherTransport {
     RAYZ_GATHER_RCCL = 0,     /* ncclGather to devices[0] (librccl.so.1 is opened at the first multi-device call) */
     RAYZ_GATHER_PEER_COPY = 1 /* hipMemcpyPeerAsync into devices[0] */

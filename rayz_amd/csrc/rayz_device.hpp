@@ -34,10 +34,11 @@ constexpr int kMaxTextureDepth = 8;
 #ifndef RAYZ_GROUP
 #define RAYZ_GROUP 4
 #endif
-// spheres per scan group (and per SoA block of a stream): 4 for f32, 2 for f64 — the two ping-pong SGPR sets of a
-// y-moving group are 2 x 5 x G registers of R, and more than ~40 SGPRs spill inside the loop
+// spheres per scan group (and per SoA block of a stream): 4 — the two ping-pong SGPR sets of a y-moving group are
+// 2 x 5 x G registers, and more than ~40 SGPRs spill inside the loop.  (The scan streams are f32 for both precisions;
+// group_size<double> = 2 belonged to the f64 streams the f64 kernel scanned until round 2.)
 template <class R> constexpr int group_size() { return sizeof(R) == 8 ? RAYZ_GROUP / 2 : RAYZ_GROUP; }
-constexpr int kStaticGroup = RAYZ_GROUP; // (f32 values; use group_size<R>())  A stream is padded to a whole
+constexpr int kStaticGroup = RAYZ_GROUP; // A stream is padded to a whole
 constexpr int kMovYGroup = RAYZ_GROUP;   //   number of group PAIRS plus two spare groups, so that the prefetch of the
 constexpr int kMovGGroup = 2;   //   next group never leaves the array.
 constexpr int kTriGroup = 2;
@@ -48,14 +49,15 @@ template <> struct VecOf<double> { typedef d4 type; typedef d2 pair; };
 
 // ---- device-resident scene (HBM layout) ------------------------------------------
 // Scan streams, one per velocity class, each padded with never-hit records (r² = -inf):
-//   static  v = 0            stat: blocks of G = group_size<R>() spheres (4 in f32, 2 in f64), SoA inside a block:
+//   static  v = 0            stat: blocks of G = 4 spheres, SoA inside a block:
 //                                  cx[G] cy[G] cz[G] r²[G]
 //   mov-Y   v = (0, vy, 0)   movy: blocks of G: cx[G] cy[G] cz[G] r²[G] vy[G]
 //                            (what randomBouncing makes)
 //   mov-G   any other v      movg[2i] = {cx, cy, cz, r²}, movg[2i+1] = {vx, vy, vz, 0}
 // The block layout puts the same field of two neighbouring spheres in one aligned SGPR pair, which is what a
 // v_pk_fma_f32 takes as a single scalar operand.  A "slot" numbers the records stat | movy | movg
-// in that order.  The f64 copies feed the narrow phase.
+// in that order.  All three are f32 for both precisions (the reject test only filters); the f64
+// copies feed the narrow phase.
 template <class R> struct DevScene {
     typedef typename VecOf<R>::type r4;
     const float* stat;       // [4 * ns_pad + spare block]   (the scan streams are f32 for both precisions: the reject test
