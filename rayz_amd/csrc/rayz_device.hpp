@@ -1255,6 +1255,12 @@ template <class R> __global__ __launch_bounds__(256, bvh_waves<R>()) void trace_
     // workgroup (A.bvh_top_words u32s; a node's LDS address is its index << 6 for f32), then the per-lane traversal stacks,
     // sized by the launch from the tree's depth: entry s of this lane at stack[256 * s] — conflict-free for any mix of s
     extern __shared__ uint32_t lds_words[];
+    // the node fetch addresses the LDS copy by index << 6 from LDS address 0: refuse to run (loudly: the host turns the
+    // flag into RAYZ_ERR_STATE) should a build ever place anything in front of the dynamic segment
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)lds_words != 0u) {
+        if (threadIdx.x == 0) A.counters[31] = 1ull;
+        return;
+    }
     f4* top = (f4*)lds_words;
     uint32_t* stack = lds_words + A.bvh_top_words + threadIdx.x;
     for (uint32_t k = threadIdx.x; k < 4u * A.sc.bvh_top; k += 256u) top[k] = A.sc.bvh_nodes[k];

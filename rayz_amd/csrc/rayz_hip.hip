@@ -881,6 +881,8 @@ int scene_sync(RayzScene* s, RayzRenderStats* stats) {
                          100.0 * (double)c[19] / (double)(c[5] ? c[5] : 1), (double)c[19] / it);
         }
 #endif
+        if (s->last_bvh && c[31])
+            return fail(RAYZ_ERR_STATE, "trace_kernel_bvh refused to run: its dynamic LDS segment does not start at LDS address 0");
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
         s->last.segments = c[1];
