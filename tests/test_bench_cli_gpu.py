@@ -35,7 +35,8 @@ def test_bench_json_contract(gpu):
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["unit"] == "Msamples/s" and cb["value"] > 0 and cb["sample"]
     assert d["value"] > 0 and abs(d["value"] - 96 * 54 * 4 * 2 / (d["ms_per_step"] * 2e-3) / 1e6) < 1e-6 * d["value"] + 1e-9
     assert d["also"]["bvh_traversal"]["value"] > 0 and d["also"]["bvh_traversal"]["roofline"]["frac"] > 0
-    assert d["also"]["f64_flat_list"]["value"] > 0 and d["also"]["f64_bvh_traversal"]["roofline"]["bound"] == "valu_fp64"
+    # (the f64 fidelity mode's filters — reject tests, box walk — run in f32: its kernels are priced against the FP32 peak)
+    assert d["also"]["f64_flat_list"]["value"] > 0 and d["also"]["f64_bvh_traversal"]["roofline"]["bound"] == "valu_fp32"
     m = d["also"]["c_abi_multi_device_entry"]  # rayz_hip_multi_render on one device: RCCL really ran
     assert m["value"] > 0 and m["n_devices"] == 1 and m["rccl_version"] > 0 and m["identical_to_device_path"] is True
     hb = d["roofline"]["hbm"]
