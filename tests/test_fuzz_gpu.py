@@ -104,6 +104,31 @@ def test_axis_scene_parity(gpu, oracle, seed):
             assert gst.segments == ost.segments
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_big_scene_flat_list_equals_bvh(gpu, oracle, seed):
+    """tools/fuzz_big.py's generator (200-3,000 spheres, triangles, an oversized ground or not: trees deeper than the
+    LDS copy of their top): flat list == BVH exactly on the device in both precisions; one scene against the oracle."""
+    import importlib.util
+    import os
+
+    spec = importlib.util.spec_from_file_location("fuzz_big_gen", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_big.py"))
+    src = open(spec.origin).read().split("first, count = int(sys.argv[1])")[0]  # the generator, not the campaign loop
+    ns = {"__file__": spec.origin}
+    exec(compile(src, spec.origin, "exec"), ns)
+    t = ns["big_scene"](seed)
+    for prec in (capi.PRECISION_F32, capi.PRECISION_F64):
+        got = {}
+        for trav in (capi.TRAVERSAL_LINEAR, capi.TRAVERSAL_BVH):
+            t.set_gpu(traversal=trav, precision=prec)
+            got[trav] = gpu.render_host(t.scene_desc(), t.camera_desc(), t.params())
+        a, b = got[capi.TRAVERSAL_LINEAR], got[capi.TRAVERSAL_BVH]
+        assert np.array_equal(a[0], b[0], equal_nan=True) and a[1].segments == b[1].segments, (seed, prec)
+        if seed == 0:
+            want, ost = oracle.render_b(t.scene_desc(), t.camera_desc(), t.params())
+            assert_images_equal(b[0], want, f"big scene {seed} precision {prec}")
+            assert b[1].segments == ost.segments
+
+
 # 1000..1011, and three scenes on which the BVH walk once lost hits to a zero direction component (tests/test_kat_cpu.py)
 @pytest.mark.parametrize("seed", list(range(1000, 1012)) + [5003, 5008, 5010])
 def test_random_scene_parity(gpu, oracle, seed):
