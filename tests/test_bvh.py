@@ -185,6 +185,21 @@ def test_gpu_bvh_equals_flat_list_on_the_whole_config3_frame(gpu):
 
 
 @pytest.mark.gpu
+def test_gpu_bvh_equals_flat_list_at_baseline_config3_in_full(gpu):
+    """BASELINE.json configs[2] exactly — 10,003 spheres, 1920x1080, 1024 spp, 50 bounces: 2.1e9 paths, 6.3e9 segments
+    through the flat list (the headline kernel, ~9 s) and through the BVH on the device: the same image bit for bit, the
+    same segment count, no non-finite pixel."""
+    t = tracer.randomBouncing(1920, -50, 50, seed=42)
+    t.samples_per_px = 1024
+    t.set_gpu(render_seed=1, traversal=capi.TRAVERSAL_BVH)
+    bvh, bst = gpu.render_host(t.scene_desc(), t.camera_desc(), t.params())
+    t.set_gpu(traversal=capi.TRAVERSAL_LINEAR)
+    flat, fst = gpu.render_host(t.scene_desc(), t.camera_desc(), t.params())
+    assert np.array_equal(bvh, flat) and bst.segments == fst.segments and np.isfinite(flat).all()
+    assert fst.primary_rays == 1920 * 1080 * 1024 and 2.9 < fst.segments / fst.primary_rays < 3.0
+
+
+@pytest.mark.gpu
 def test_gpu_bvh_edge_cases(gpu, oracle):
     for name in ("one", "coincident", "three"):
         t = dict(_scenes())[name]
