@@ -200,6 +200,19 @@ def test_gpu_bvh_equals_flat_list_at_baseline_config3_in_full(gpu):
 
 
 @pytest.mark.gpu
+def test_gpu_f64_mode_bvh_equals_flat_list_on_whole_frames(gpu):
+    """The f64 fidelity mode (f32 filters, f64 decisions): config 3 at 64 spp and the 100k-triangle mesh of config 5 at
+    4 spp, flat list against BVH on the device — identical images and segment counts."""
+    for t, spp in ((tracer.randomBouncing(1920, -50, 50, seed=42), 64), (tracer.triangleMesh(1920, 224, seed=1), 4)):
+        t.samples_per_px = spp
+        t.set_gpu(render_seed=2, traversal=capi.TRAVERSAL_BVH, precision=capi.PRECISION_F64)
+        bvh, bst = gpu.render_host(t.scene_desc(), t.camera_desc(), t.params())
+        t.set_gpu(traversal=capi.TRAVERSAL_LINEAR)
+        flat, fst = gpu.render_host(t.scene_desc(), t.camera_desc(), t.params())
+        assert bvh.dtype == np.float64 and np.array_equal(bvh, flat) and bst.segments == fst.segments and np.isfinite(flat).all()
+
+
+@pytest.mark.gpu
 def test_gpu_bvh_edge_cases(gpu, oracle):
     for name in ("one", "coincident", "three"):
         t = dict(_scenes())[name]
