@@ -359,7 +359,9 @@ def run(args, json_fd):
                     "count the flops of the kernel's own reject test (7 / 8 / 12 FMA = 14 / 16 / 24 flop per static / "
                     "y-moving / moving sphere, DESIGN.md 4.3) x segments; `reference_formulation` prices the same frame "
                     "with SURVEY 8d's figure for the reference's quadratic (18 / 24 flop per test), which this kernel "
-                    "does not execute - that fraction can exceed 1")
+                    "does not execute - that fraction can exceed 1.  The kernel is power-limited: ~1.35 kW, shader clock "
+                    "~2.2 GHz instead of the 2.4 GHz the peak assumes (tools/clk_probe.sh, profiles/r02/clk_probe.log), so its "
+                    "rate follows the clock a given box sustains (8.8-9.3 s per frame over eight boxes)")
         else:
             st_last = dscene.sync()
             flops = (st_last.node_tests * FLOP_PER_BOX_TEST + st_last.sphere_tests * FLOP_PER_TEST_MOVING)
