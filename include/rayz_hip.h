@@ -25,8 +25,10 @@
 extern "C" {
 #endif
 
-#define RAYZ_HIP_ABI_VERSION 4u /* 2: RayzTriangle, shard fields; 3: RAYZ_TRAVERSAL_AUTO; 4: per-scene devices,
-                                   rayz_hip_multi_* (several GPUs behind one call), rayz_hip_kat, chunk_spp auto */
+#define RAYZ_HIP_ABI_VERSION 5u /* 2: RayzTriangle, shard fields; 3: RAYZ_TRAVERSAL_AUTO; 4: per-scene devices,
+                                   rayz_hip_multi_* (several GPUs behind one call), rayz_hip_kat, chunk_spp auto;
+                                   5: rayz_hip_debug_set (the library reads no environment variable),
+                                   rayz_hip_multi_device_stats / _timing, RAYZ_GATHER_ALLOW_DUPLICATE_DEVICES */
 #define RAYZ_MAX_DEVICES 64
 
 typedef enum RayzStatus {
@@ -175,6 +177,22 @@ void rayz_hip_shutdown(void);
 const char* rayz_hip_last_error(void);
 uint32_t rayz_hip_abi_version(void);
 
+/* Measurement knobs.  They change how the work is SCHEDULED or which (equivalent) tree the GPU walks — never an image —
+ * and exist for the sweep tools under tools/ and for the tests that hold the kernels against each other.  Process-wide;
+ * value < 0 restores the built-in default; takes effect for renders (BVH_PEEL / BVH_TOP: scenes) started afterwards.
+ * The library reads NO environment variable. */
+typedef enum RayzDebugKnob {
+    RAYZ_DEBUG_QUEUE_GRAB = 0, /* work items a wave reserves per atomic on the queue head (default 64) */
+    RAYZ_DEBUG_BVH_KEEP = 1,   /* one-path BVH kernel: keep_active | keep_stepping << 8 */
+    RAYZ_DEBUG_BVH_PEEL = 2,   /* 0: walk the reference's full tree (oversized hittables stay in it) */
+    RAYZ_DEBUG_BVH_TOP = 3,    /* inner-node records of the tree's top kept in LDS (default 256) */
+    RAYZ_DEBUG_BVH_KERNEL = 4, /* f32 BVH renders: 1 = one path per lane (trace_kernel_bvh, default), 2 = two (trace_kernel_bvh2) */
+    RAYZ_DEBUG_BVH2_KEEP = 5,  /* two-path BVH kernel: service | blocked << 8 | swap << 16 | keep_stepping << 24 */
+    RAYZ_DEBUG_LDS_PAD = 6,    /* BVH kernels: unused bytes added to the workgroup's LDS request (occupancy experiments) */
+    RAYZ_DEBUG_KNOBS = 7
+} RayzDebugKnob;
+int rayz_hip_debug_set(uint32_t knob, long long value);
+
 /* Number of rows the shard described by `p` owns (= rows of the compact output). */
 uint32_t rayz_hip_shard_rows(const RayzRenderParams* p);
 
@@ -233,11 +251,14 @@ int rayz_hip_render_f64(const RayzSceneDesc* scene, const RayzCameraDesc* camera
  * to the caller's HOST buffer (height*width*3, row-major RGB).  The image is bit-identical for any device count
  * (the per-(pixel,sample) streams are keyed by global pixel coordinates).  `params->shard_index/shard_count`
  * must be 0: the library shards.  Blocking; driven by the calling thread; one call at a time per handle.
- * A device may be listed once (RAYZ_ERR_BAD_ARG otherwise; the environment variable
- * RAYZ_MULTI_ALLOW_DUPLICATE_DEVICES=1 lifts that for TESTS on a one-GPU box, peer-copy transport only). */
+ * A device may be listed once (RAYZ_ERR_BAD_ARG otherwise); OR-ing RAYZ_GATHER_ALLOW_DUPLICATE_DEVICES into a
+ * PEER_COPY transport lifts that for TESTS on a one-GPU box (refused with RCCL, which cannot take a device twice).
+ * STATUS: with n > 1 DISTINCT devices this path has not yet run on hardware (the development pool has one GPU per
+ * box): n = 1 through RCCL and n = 2/3/8 on one device through peer copies are what the GPU suite exercises. */
 typedef enum RayzGatherTransport {
-    RAYZ_GATHER_RCCL = 0,     /* ncclGather to devices[0] (librccl.so.1 is opened at the first multi-device call) */
-    RAYZ_GATHER_PEER_COPY = 1 /* hipMemcpyPeerAsync into devices[0] */
+    RAYZ_GATHER_RCCL = 0,      /* ncclGather to devices[0] (librccl.so.1 is opened at the first multi-device call) */
+    RAYZ_GATHER_PEER_COPY = 1, /* hipMemcpyPeerAsync into devices[0] */
+    RAYZ_GATHER_ALLOW_DUPLICATE_DEVICES = 0x100 /* flag bit, peer-copy only: the same ordinal may be listed repeatedly */
 } RayzGatherTransport;
 
 typedef struct RayzMulti RayzMulti; /* opaque: one scene per device + communicators + gather buffers */
@@ -247,6 +268,12 @@ int rayz_hip_multi_create(const int* devices, int n_devices, const RayzSceneDesc
 int rayz_hip_multi_destroy(RayzMulti* multi);
 /* n_devices, the transport in use and RCCL's version code (0 with peer copies); any pointer may be NULL */
 int rayz_hip_multi_info(const RayzMulti* multi, int* n_devices, uint32_t* transport, int* rccl_version);
+/* After a render on the handle: device `index`'s own counters (its rows, its segments, ITS trace-kernel time — load
+ * imbalance between row shards shows here), and the frame's timing: gather_ms = on the root's stream, from "the
+ * root's rows are traced" to "the frame is assembled" (the transfer + the wait for slower devices + the
+ * un-interleave); frame_ms = host wall time of gather + copy-out.  Either pointer of _timing may be NULL. */
+int rayz_hip_multi_device_stats(const RayzMulti* multi, int index, RayzRenderStats* stats);
+int rayz_hip_multi_timing(const RayzMulti* multi, double* gather_ms, double* frame_ms);
 /* `tracer.render()` on all devices of the handle.  stats: counts summed over the devices, kernel_ms = slowest. */
 int rayz_hip_multi_render(RayzMulti* multi, const RayzCameraDesc* camera, const RayzRenderParams* params,
                           float* rgb_out, RayzRenderStats* stats_or_null);
@@ -257,7 +284,8 @@ int rayz_hip_multi_render_f64(RayzMulti* multi, const RayzCameraDesc* camera, co
  * writePPM would print.  f32 precision only. */
 int rayz_hip_multi_render_u8(RayzMulti* multi, const RayzCameraDesc* camera, const RayzRenderParams* params,
                              uint8_t* rgb8_out, RayzRenderStats* stats_or_null);
-/* One-shot forms: create, render, destroy (RCCL transport). */
+/* One-shot forms: create, render, destroy (RCCL transport).  They pay communicator creation (ncclCommInitAll, tens
+ * of milliseconds per device) on EVERY call: a caller that renders more than one frame keeps a RayzMulti. */
 int rayz_hip_render_multi(const int* devices, int n_devices, const RayzSceneDesc* scene,
                           const RayzCameraDesc* camera, const RayzRenderParams* params, float* rgb_out,
                           RayzRenderStats* stats_or_null);

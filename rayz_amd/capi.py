@@ -12,9 +12,12 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "librayz_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_DEVICES = 64
 GATHER_RCCL, GATHER_PEER_COPY = 0, 1
+GATHER_ALLOW_DUPLICATE_DEVICES = 0x100  # flag bit, peer-copy only (tests on a one-GPU box)
+(DEBUG_QUEUE_GRAB, DEBUG_BVH_KEEP, DEBUG_BVH_PEEL, DEBUG_BVH_TOP, DEBUG_BVH_KERNEL, DEBUG_BVH2_KEEP,
+ DEBUG_LDS_PAD) = range(7)
 (KAT_REFRACT, KAT_REFLECTANCE, KAT_GET_RAY, KAT_BOX_HIT, KAT_SPHERE_HIT, KAT_SCATTER, KAT_CHECKER, KAT_BACKGROUND,
  KAT_TRIANGLE_HIT) = range(9)
 KAT_IN_STRIDE, KAT_OUT_STRIDE = 48, 12
@@ -87,6 +90,7 @@ PROTOTYPES = [
     ("rayz_hip_shutdown", None, []),
     ("rayz_hip_last_error", C.c_char_p, []),
     ("rayz_hip_abi_version", C.c_uint32, []),
+    ("rayz_hip_debug_set", C.c_int, [C.c_uint32, C.c_longlong]),
     ("rayz_hip_shard_rows", C.c_uint32, [C.POINTER(RenderParams)]),
     ("rayz_hip_chunk_schedule", C.c_uint32, [C.POINTER(RenderParams), C.POINTER(C.c_uint32), C.c_uint32]),
     ("rayz_hip_scene_create", C.c_int, [C.POINTER(SceneDesc), C.POINTER(C.c_void_p)]),
@@ -112,6 +116,8 @@ PROTOTYPES = [
      [C.POINTER(C.c_int), C.c_int, C.POINTER(SceneDesc), C.c_uint32, C.POINTER(C.c_void_p)]),
     ("rayz_hip_multi_destroy", C.c_int, [C.c_void_p]),
     ("rayz_hip_multi_info", C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
+    ("rayz_hip_multi_device_stats", C.c_int, [C.c_void_p, C.c_int, C.POINTER(RenderStats)]),
+    ("rayz_hip_multi_timing", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("rayz_hip_multi_render", C.c_int,
      [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderParams), C.c_void_p, C.POINTER(RenderStats)]),
     ("rayz_hip_multi_render_f64", C.c_int,

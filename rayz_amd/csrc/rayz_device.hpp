@@ -1013,6 +1013,18 @@ __device__ __forceinline__ float min_bound(float x, float bound) {
     return r;
 }
 
+template <class R> struct LeafBasis;
+template <> struct LeafBasis<float> {
+    RayBasis<float> b;
+    __device__ __forceinline__ void make(V<float> ud, V<float> o) { b = make_basis<float>(ud, o); }
+    __device__ __forceinline__ RayBasis<float> get(V<float>, V<float>) const { return b; }
+};
+template <> struct LeafBasis<double> {
+    __device__ __forceinline__ void make(V<double>, V<double>) {}
+    __device__ __forceinline__ RayBasis<float> get(V<double> ud, V<double> o) const {
+        return make_basis<float>(V<float>{(float)ud.x, (float)ud.y, (float)ud.z}, V<float>{(float)o.x, (float)o.y, (float)o.z});
+    }
+};
 template <class R> struct BvhQuery {
     // the slab test runs in f32 whatever R is: it only culls, and stays conservative under the conversion (§4.8)
     V<float> inv;   // 1 / d per component (capped, bvh_begin)
@@ -1025,6 +1037,10 @@ template <class R> struct BvhQuery {
     uint32_t cur;   // what the lane holds: an inner node to visit (< kBvhDone), a parked leaf (kBvhLeafFlag | descriptor),
                     // or kBvhDone — then the stack is empty as well and the walk is complete
     uint32_t sp;    // index of the stack's top entry; entry 0 is a kBvhDone sentinel, so popping an empty stack ends the walk
+    // the reject test's orthonormal pair, made once per segment by the set-up instead of once per leaf
+    // phase (a square root and a division, ≈35 vector instructions, ≈3 times per segment at ≈26 lanes).  R = float only: the
+    // f64 kernel sits at 128 VGPRs and keeps making it at the leaves (LeafBasis<double> is empty).
+    LeafBasis<R> lb;
 };
 
 // Slack of the f32 slab test.  R = float: relative 1 + 4 ulp (= 8u, u = 2^-24) and absolute 4u·Σ|noi|, against a need of
@@ -1049,7 +1065,8 @@ constexpr float kInvCap = 0x1p64f;
 __device__ __forceinline__ float capped_inverse(float dk) { // (one v_med3_f32 behind the division)
     return __builtin_amdgcn_fmed3f(1.0f / dk, -kInvCap, kInvCap);
 }
-template <class R> __device__ __forceinline__ void bvh_begin(BvhQuery<R>& q, V<R> o, V<R> d, uint32_t n_inner) {
+template <class R> __device__ __forceinline__ void bvh_begin(BvhQuery<R>& q, V<R> o, V<R> d, V<R> ud, uint32_t n_inner) {
+    q.lb.make(ud, o);
     if constexpr (sizeof(R) == 8) { // d_k narrowed to f32 first; a component beyond f32's range would make inv 0: held to ±2^100
         q.inv = {capped_inverse(__builtin_amdgcn_fmed3f((float)d.x, -0x1p100f, 0x1p100f)),
                  capped_inverse(__builtin_amdgcn_fmed3f((float)d.y, -0x1p100f, 0x1p100f)),
@@ -1096,7 +1113,7 @@ __device__ __forceinline__ bool bvh_box_hit(f4 lo, f4 hi, const BvhQuery<R>& q, 
 // top when there is nothing to push, the pop is a read every stepping lane makes.  `stack` is this lane's column of
 // the workgroup's LDS stack (entry s at stack[s * 256]).
 template <class R>
-__device__ __forceinline__ void bvh_node_step(const DevScene<R>& sc, BvhQuery<R>& q, float tmin, uint32_t* stack
+__device__ __forceinline__ void bvh_node_step(const DevScene<R>& sc, const f4* nodes_base, BvhQuery<R>& q, float tmin, uint32_t* stack
 #ifdef RAYZ_BVH_PROFILE
                                               , unsigned long long& g_fetch_ticks
 #endif
@@ -1130,7 +1147,7 @@ __device__ __forceinline__ void bvh_node_step(const DevScene<R>& sc, BvhQuery<R>
                      "s_mov_b64 exec, %[sv]\n\t"
                      "s_waitcnt vmcnt(0) lgkmcnt(0)"
                      : [n0] "=&v"(llo), [n1] "=&v"(lhi), [n2] "=&v"(rlo), [n3] "=&v"(rhi), [sv] "=&s"(saved)
-                     : [off] "v"(off), [mt] "s"(in_top), [base] "s"(sc.bvh_nodes)
+                     : [off] "v"(off), [mt] "s"(in_top), [base] "s"(nodes_base)
                      : "memory", "scc");
     }
 #ifdef RAYZ_BVH_PROFILE // time from issuing the node fetch to having it (the wave's own view), accumulated in g_prof_fetch
@@ -1160,6 +1177,14 @@ template <class R> __device__ __forceinline__ void bvh_pop(BvhQuery<R>& q, const
     q.sp -= 1u;
 }
 
+// The reject test of a leaf entry (general velocity form of DESIGN.md §4.3, f32 for both precisions): the ONE place it is
+// written — the BVH kernels' leaves, the oversized hittables and the known-answer entry all call it.
+__device__ __forceinline__ bool leaf_reject_test(const RayBasis<float>& b, float ft, V<float> c, V<float> v, float r2_padded) {
+    const float p1 = fm(v.z, ft * b.e1z, fm(v.x, ft * b.e1x, basis_p1<float>(b, c.x, c.z)));
+    const float p2 = fm(v.z, ft * b.e2z, fm(v.y, ft * b.e2y, fm(v.x, ft * b.e2x, basis_p2<float>(b, c.x, c.y, c.z))));
+    return sphere_candidate<float>(p1, p2, r2_padded);
+}
+
 // Phase L — entry k of a parked leaf: a triangle is decided here (R arithmetic only); a sphere gets the reject
 // test in R and, if its line meets the sphere, is parked as a candidate (slot + 1) for phase C.
 template <class R>
@@ -1177,11 +1202,9 @@ __device__ __forceinline__ uint32_t bvh_leaf_entry(const DevScene<R>& sc, BvhQue
     }
     // the flat list's reject test: in f32 for both precisions, on the ray narrowed to f32 (hipcc shares the basis between
     // both entries of a leaf); c.w = the f32 padded square
-    const RayBasis<float> b = make_basis<float>(V<float>{(float)ud.x, (float)ud.y, (float)ud.z}, V<float>{(float)o.x, (float)o.y, (float)o.z});
-    const float ft = (float)time, vx = (float)v.x, vy = (float)v.y, vz = (float)v.z;
-    const float p1 = fm(vz, ft * b.e1z, fm(vx, ft * b.e1x, basis_p1<float>(b, (float)c.x, (float)c.z)));
-    const float p2 = fm(vz, ft * b.e2z, fm(vy, ft * b.e2y, fm(vx, ft * b.e2x, basis_p2<float>(b, (float)c.x, (float)c.y, (float)c.z))));
-    return sphere_candidate<float>(p1, p2, (float)c.w) ? slot + 1u : 0u;
+    const RayBasis<float> b = q.lb.get(ud, o);
+    return leaf_reject_test(b, (float)time, V<float>{(float)c.x, (float)c.y, (float)c.z}, V<float>{(float)v.x, (float)v.y, (float)v.z}, (float)c.w)
+               ? slot + 1u : 0u;
 }
 
 // Phase C — the f64 quadratic of a parked sphere candidate (same arithmetic as narrow_phase()).
@@ -1251,6 +1274,7 @@ template <class R> __global__ __launch_bounds__(256, bvh_waves<R>()) void trace_
     q.ibest = -1;
     q.cur = kBvhDone;
     q.sp = 0;
+    q.lb.make(ud, o);
     // dynamic shared memory, from LDS address 0 (the kernel has no static LDS): the top of the tree, copied once per
     // workgroup (A.bvh_top_words u32s; a node's LDS address is its index << 6 for f32), then the per-lane traversal stacks,
     // sized by the launch from the tree's depth: entry s of this lane at stack[256 * s] — conflict-free for any mix of s
@@ -1324,7 +1348,7 @@ template <class R> __global__ __launch_bounds__(256, bvh_waves<R>()) void trace_
         //      for the per-segment set-up (unit direction, slab constants) ----
         if (fresh) {
             ud = unit(d);
-            bvh_begin<R>(q, o, d, n_nodes);
+            bvh_begin<R>(q, o, d, ud, n_nodes);
         }
         // .. then the oversized hittables kept out of the tree: the walk starts with their tbest and culls behind it
         if (A.sc.bvh_n_big_leaves != 0u && __ballot(fresh) != 0ull) {
@@ -1357,9 +1381,9 @@ template <class R> __global__ __launch_bounds__(256, bvh_waves<R>()) void trace_
                 px3[0] += __popcll(__ballot((int32_t)q.cur < 0));
                 px3[1] += __popcll(__ballot(alive && q.cur == kBvhDone));
                 px3[2] += __popcll(__ballot(!alive));
-                if (can_step) bvh_node_step<R>(A.sc, q, tmin32, stack, fetch_ticks);
+                if (can_step) bvh_node_step<R>(A.sc, A.sc.bvh_nodes, q, tmin32, stack, fetch_ticks);
 #else
-                if (can_step) bvh_node_step<R>(A.sc, q, tmin32, stack);
+                if (can_step) bvh_node_step<R>(A.sc, A.sc.bvh_nodes, q, tmin32, stack);
 #endif
                 node_tests += 2u * (uint32_t)n_can;
             }
@@ -1416,6 +1440,304 @@ template <class R> __global__ __launch_bounds__(256, bvh_waves<R>()) void trace_
         for (int k = 0; k < 7; ++k) atomicAdd(&A.counters[9 + k], pl[k]);
         for (int k = 0; k < 3; ++k) atomicAdd(&A.counters[16 + k], px3[k]);
         atomicAdd(&A.counters[19], fetch_ticks);
+    }
+#endif
+    unsigned long long t0 = nseg, t1 = node_tests, t2 = sphere_tests;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        t0 += __shfl_xor(t0, off);
+        t2 += __shfl_xor(t2, off);
+    }
+    if (lane == 0) {
+        atomicAdd(&A.counters[1], t0);
+        atomicAdd(&A.counters[2], t1);
+        atomicAdd(&A.counters[3], t2);
+    }
+}
+
+// ---- persistent trace kernel, BVH traversal, TWO paths per lane -------------------------------------------------
+// trace_kernel_bvh above issues its box steps for ~39 of 64 lanes (profiles/r02): a lane whose walk is complete sits idle
+// until enough lanes have finished to make the long shading pass worth running (≈14 lanes on average), and the pass
+// itself then runs for the ~45 lanes that are ready.  Here every lane owns TWO path contexts.  One is held by the lane's
+// walker (ray + traversal state, in the registers the box step works on); the other is PARKED: either waiting for the
+// service pass (shade → retire / pop / start the next path → per-segment set-up) or READY with a ray whose set-up is done.
+// A lane whose walk completes swaps — a couple of dozen register moves, no arithmetic — and walks on; the service pass
+// runs when most lanes have a parked context that needs it, so it runs on (nearly) full batches, and nobody waits for it
+// while its other path still walks.  Same work items, queue, per-path arithmetic and summation tree as the other kernels:
+// images are identical bit for bit; only which lane traces which item, and when, differs.
+template <class R> struct PathCtx { // what a path carries between its segments, besides its ray
+    Pcg32 g;
+    V<R> thr, acc;
+    uint32_t item, px, py, s_cur, s_end, seg;
+    bool has_item;
+};
+template <class T> __device__ __forceinline__ T pick(bool s, T if_set, T if_clear) { return s ? if_set : if_clear; }
+template <class R> __device__ __forceinline__ V<R> pick(bool s, V<R> a, V<R> b) { return {s ? a.x : b.x, s ? a.y : b.y, s ? a.z : b.z}; }
+template <class R> __device__ __forceinline__ PathCtx<R> ctx_pick(bool s, const PathCtx<R>& c1, const PathCtx<R>& c0) {
+    PathCtx<R> c;
+    c.g.state = pick(s, c1.g.state, c0.g.state);
+    c.g.inc = pick(s, c1.g.inc, c0.g.inc);
+    c.thr = pick<R>(s, c1.thr, c0.thr);
+    c.acc = pick<R>(s, c1.acc, c0.acc);
+    c.item = pick(s, c1.item, c0.item);
+    c.px = pick(s, c1.px, c0.px);
+    c.py = pick(s, c1.py, c0.py);
+    c.s_cur = pick(s, c1.s_cur, c0.s_cur);
+    c.s_end = pick(s, c1.s_end, c0.s_end);
+    c.seg = pick(s, c1.seg, c0.seg);
+    c.has_item = pick(s, c1.has_item, c0.has_item);
+    return c;
+}
+template <class R> __device__ __forceinline__ void ctx_init(PathCtx<R>& c) {
+    c.g = Pcg32{0, 1};
+    c.thr = {R(1), R(1), R(1)};
+    c.acc = {R(0), R(0), R(0)};
+    c.item = c.px = c.py = c.s_cur = c.s_end = c.seg = 0;
+    c.has_item = false;
+}
+// state of a lane's parked context
+constexpr uint32_t kParkIdle = 0;  // no path in flight: retire the finished chunk / pop an item / start the next path
+constexpr uint32_t kParkDone = 1;  // its walk is complete: shade, then as above
+constexpr uint32_t kParkReady = 2; // holds a ray with its set-up done: the walker can take it
+constexpr uint32_t kParkDead = 3;  // no item and the queue has run dry: nothing left to do for this context
+// scheduling thresholds (defaults; TraceArgs::bvh_keep carries the values in use — they change no result)
+constexpr int kBvh2Service = 40; // run the service pass when this many lanes have a parked context waiting for it ..
+constexpr int kBvh2Blocked = 10; // .. or when this many lanes can do nothing else (their walker is idle, too)
+constexpr int kBvh2Swap = 6;     // run the swap when this many lanes have an idle walker and a ready ray
+#ifndef RAYZ_BVH2_WAVES
+#define RAYZ_BVH2_WAVES 3 // both contexts live in registers: 168 VGPRs
+#endif
+template <class R> __global__ __launch_bounds__(256, RAYZ_BVH2_WAVES) void trace_kernel_bvh2(const TraceArgs<R> A) {
+    typedef typename VecOf<R>::type r4;
+    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const uint32_t n_nodes = A.sc.bvh_n_nodes;
+    const int t_service = (int)(A.bvh_keep & 0xffu), t_blocked = (int)((A.bvh_keep >> 8) & 0xffu),
+              t_swap = (int)((A.bvh_keep >> 16) & 0xffu), keep_stepping = (int)((A.bvh_keep >> 24) & 0xffu);
+    const float tmin32 = round_down_f32(A.tmin);
+    extern __shared__ uint32_t lds_words[];
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)lds_words != 0u) { // see trace_kernel_bvh
+        if (threadIdx.x == 0) A.counters[31] = 1ull;
+        return;
+    }
+    f4* top = (f4*)lds_words;
+    uint32_t* stack = lds_words + A.bvh_top_words + threadIdx.x;
+    for (uint32_t k = threadIdx.x; k < 4u * A.sc.bvh_top; k += 256u) top[k] = A.sc.bvh_nodes[k];
+    stack[0] = kBvhDone;
+    __syncthreads();
+
+    // the node array's base as scalar registers of its own (the step's global loads take it as their SGPR base: under this
+    // kernel's scalar-register pressure hipcc otherwise hands the inline assembly a VGPR pair)
+    const f4* nodes_base;
+    {
+        const unsigned long long nb = (unsigned long long)(uintptr_t)A.sc.bvh_nodes;
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)nb), hi = __builtin_amdgcn_readfirstlane((uint32_t)(nb >> 32));
+        nodes_base = (const f4*)(uintptr_t)((unsigned long long)lo | ((unsigned long long)hi << 32));
+    }
+    PathCtx<R> c0, c1; // the lane's two path contexts; the walker's is c[wsel], the parked one c[wsel ^ 1]
+    ctx_init<R>(c0);
+    ctx_init<R>(c1);
+    // the walker
+    V<R> o{0, 0, 0}, d{0, 0, 1}, ud{0, 0, 1};
+    R time = 0;
+    BvhQuery<R> q;
+    q.inv = {1.0f, 1.0f, 1.0f};
+    q.noi = {0.0f, 0.0f, 0.0f};
+    q.eb = 0.0f;
+    q.tb32 = 0.0f;
+    q.inv_a2 = 1.0;
+    q.tbest = R(0);
+    q.ibest = -1;
+    q.cur = kBvhDone;
+    q.sp = 0;
+    q.lb.make(ud, o);
+    bool w_has = false; // the walker holds a context (walking while q.cur != kBvhDone, complete after)
+    bool wsel = false;
+    // the parked context's ray: complete (kParkDone: o, d, ud, time, tbest, ibest) or ready (kParkReady: everything)
+    V<R> po{0, 0, 0}, pd{0, 0, 1}, pud{0, 0, 1};
+    R ptime = 0;
+    BvhQuery<R> pq = q;
+    uint32_t p_state = kParkIdle;
+    uint32_t nseg = 0, sphere_tests = 0, node_tests = 0;
+    WaveQueue wq;
+#ifdef RAYZ_BVH_PROFILE
+    unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, pl[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, px3[3] = {0, 0, 0}, pt0 = __builtin_amdgcn_s_memtime();
+#define RAYZ_PROF2_T(k) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); pt[k] += now_ - pt0; pt0 = now_; }
+#define RAYZ_PROF2_L(k, n) { pl[k] += (unsigned long long)(n); pl[k + 1] += 1; }
+#else
+#define RAYZ_PROF2_T(k)
+#define RAYZ_PROF2_L(k, n)
+#endif
+
+    for (;;) {
+        // ---- service pass: parked contexts that wait for it (wave-uniform decision) ----
+        const bool want_service = p_state == kParkIdle || p_state == kParkDone;
+        const unsigned long long m_service = __ballot(want_service), m_walking = __ballot(q.cur != kBvhDone);
+        const int n_service = __popcll(m_service), n_walking = __popcll(m_walking), n_blocked = __popcll(m_service & ~m_walking);
+        bool progressed = false;
+        if (n_service != 0 && (n_service >= t_service || n_blocked >= t_blocked || n_walking == 0)) {
+            progressed = true;
+            RAYZ_PROF2_L(0, n_service)
+            PathCtx<R> c = ctx_pick<R>(!wsel, c1, c0); // the parked context: c[wsel ^ 1]
+            bool alive = false;
+            if (p_state == kParkDone) { // shade the completed segment
+                nseg++;
+                c.seg++;
+                bool cont = shade<R>(A.sc, c.g, po, pd, pud, ptime, pq.tbest, pq.ibest, c.thr, c.acc);
+                if (c.seg >= A.max_bounces) cont = false;
+                alive = cont;
+            }
+            if (want_service && !alive && c.has_item && c.s_cur == c.s_end) { // retire the finished chunk
+                A.partial[c.item] = r4{c.acc.x, c.acc.y, c.acc.z, R(0)};
+                c.has_item = false;
+            }
+            {
+                const bool need = want_service && !alive && !c.has_item && !queue_empty<R>(wq, A);
+                const bool popping = __ballot(need) != 0ull;
+                uint32_t got_item = 0;
+                if (queue_pop<R>(A, wq, lane, need, got_item)) {
+                    c.item = got_item;
+                    c.has_item = true;
+                    const uint32_t k = c.item / A.shard_pixels, lp = c.item - k * A.shard_pixels;
+                    const uint32_t lr = lp / A.width;
+                    c.px = lp - lr * A.width;
+                    const uint32_t tl = lr / A.tile_rows, within = lr - tl * A.tile_rows;
+                    c.py = (tl * A.shard_count + A.shard_index) * A.tile_rows + within;
+                    c.s_cur = A.chunk_start[k];
+                    c.s_end = A.chunk_start[k + 1];
+                    c.acc = {R(0), R(0), R(0)};
+                }
+                if (popping && node_tests > RAYZ_STAT_SPILL) { // (see trace_kernel_bvh)
+                    if (lane == 0) atomicAdd(&A.counters[2], (unsigned long long)node_tests);
+                    atomicAdd(&A.counters[3], (unsigned long long)sphere_tests);
+                    atomicAdd(&A.counters[1], (unsigned long long)nseg);
+                    node_tests = sphere_tests = nseg = 0;
+                }
+            }
+            bool fresh = alive;
+            if (want_service && !alive && c.has_item) { // start the next path of the chunk
+                const unsigned long long pixel_index = (unsigned long long)c.py * A.width + c.px;
+                c.g.seed_path(A.seed, pixel_index * A.spp + c.s_cur);
+                camera_ray<R>(A.cam, c.g, c.px, c.py, po, pd, ptime);
+                c.thr = {R(1), R(1), R(1)};
+                c.seg = 0;
+                c.s_cur++;
+                fresh = true;
+            }
+            // the per-segment set-up of every ray made above (scattered or camera), then the oversized hittables kept
+            // out of the tree: the walk starts with their tbest
+            if (fresh) {
+                pud = unit(pd);
+                bvh_begin<R>(pq, po, pd, pud, n_nodes);
+            }
+            if (A.sc.bvh_n_big_leaves != 0u && __ballot(fresh) != 0ull) {
+                if (fresh) {
+                    for (uint32_t k = 0; k < A.sc.bvh_n_big_leaves; ++k) {
+                        const uint32_t desc = A.sc.bvh_big[k];
+                        sphere_tests += desc & 3u;
+                        const uint32_t b0 = bvh_leaf_entry<R>(A.sc, pq, desc, 0u, po, pd, pud, ptime, A.tmin);
+                        const uint32_t b1 = (desc & 3u) > 1u ? bvh_leaf_entry<R>(A.sc, pq, desc, 1u, po, pd, pud, ptime, A.tmin) : 0u;
+                        if (b0 != 0u) bvh_candidate<R>(A.sc, pq, b0 - 1u, po, pd, ptime, A.tmin);
+                        if (b1 != 0u) bvh_candidate<R>(A.sc, pq, b1 - 1u, po, pd, ptime, A.tmin);
+                    }
+                }
+            }
+            if (want_service) {
+                p_state = fresh ? kParkReady : kParkDead;
+                if (wsel) c0 = c; else c1 = c;
+            }
+            RAYZ_PROF2_T(0)
+        }
+        // ---- swap: an idle walker takes the parked ray; the segment it completed is parked for the service pass ----
+        {
+            const bool w_idle = q.cur == kBvhDone;
+            const bool can_swap = w_idle && (p_state == kParkReady || (w_has && p_state == kParkDead));
+            const unsigned long long m_swap = __ballot(can_swap), m_walk2 = __ballot(!w_idle);
+            const int n_swap = __popcll(m_swap);
+            if (n_swap != 0 && (n_swap >= t_swap || progressed || m_walk2 == 0ull)) {
+                progressed = true;
+                RAYZ_PROF2_L(2, n_swap)
+                if (can_swap) {
+                    const bool take = p_state == kParkReady, give = w_has;
+                    const V<R> to = o, td = d, tud = ud;
+                    const R tt = time, ttb = q.tbest;
+                    const int tib = q.ibest;
+                    if (take) {
+                        o = po, d = pd, ud = pud, time = ptime;
+                        q = pq; // bvh_begin left cur at the root and the stack empty
+                    }
+                    if (give) {
+                        po = to, pd = td, pud = tud, ptime = tt;
+                        pq.tbest = ttb, pq.ibest = tib;
+                    }
+                    p_state = give ? kParkDone : kParkIdle; // (the context a walker without one leaves behind holds no item)
+                    w_has = take;
+                    wsel = !wsel;
+                }
+                RAYZ_PROF2_T(1)
+            }
+        }
+        if (__ballot(q.cur != kBvhDone) == 0ull) {
+            if (!progressed) break; // nobody walks, nothing to swap, nothing to service: the wave is done
+            continue;
+        }
+
+        // ---- rounds of (N) box steps, (L) leaf tests, (C) candidate roots on the walkers ----
+        const unsigned long long m_ready = __ballot(p_state == kParkReady || (w_has && p_state == kParkDead)),
+                                 m_service2 = __ballot(p_state == kParkIdle || p_state == kParkDone);
+        const int n_service2 = __popcll(m_service2);
+        for (;;) {
+            if constexpr (sizeof(R) == 8) q.tb32 = round_up_f32(q.tbest);
+            for (;;) { // phase N
+                const bool can_step = q.cur < kBvhDone;
+                const int n_can = __popcll(__ballot(can_step));
+                if (n_can == 0) break;
+                if (n_can < keep_stepping && __ballot((int32_t)q.cur < 0) != 0ull) break;
+                RAYZ_PROF2_L(4, n_can)
+#ifdef RAYZ_BVH_PROFILE
+                px3[0] += __popcll(__ballot((int32_t)q.cur < 0));
+                px3[1] += __popcll(__ballot(q.cur == kBvhDone));
+                unsigned long long ft_ = 0;
+                if (can_step) bvh_node_step<R>(A.sc, nodes_base, q, tmin32, stack, ft_);
+#else
+                if (can_step) bvh_node_step<R>(A.sc, nodes_base, q, tmin32, stack);
+#endif
+                node_tests += 2u * (uint32_t)n_can;
+            }
+            RAYZ_PROF2_T(2)
+            const bool parked = (int32_t)q.cur < 0;
+            if (__ballot(parked) != 0ull) {
+                RAYZ_PROF2_L(6, __popcll(__ballot(parked)))
+                uint32_t cand0 = 0, cand1 = 0;
+                if (parked) { // phase L
+                    const uint32_t leaf = q.cur & ~kBvhLeafFlag;
+                    sphere_tests += leaf & 3u;
+                    cand0 = bvh_leaf_entry<R>(A.sc, q, leaf, 0u, o, d, ud, time, A.tmin);
+                    if ((leaf & 3u) > 1u) cand1 = bvh_leaf_entry<R>(A.sc, q, leaf, 1u, o, d, ud, time, A.tmin);
+                    bvh_pop<R>(q, stack);
+                }
+                RAYZ_PROF2_T(3)
+                if (__ballot((cand0 | cand1) != 0u) != 0ull) { // phase C
+                    RAYZ_PROF2_L(8, __popcll(__ballot((cand0 | cand1) != 0u)))
+                    const uint32_t k0 = cand0 != 0u ? cand0 : cand1, k1 = cand0 != 0u ? cand1 : 0u;
+                    if (k0 != 0u) bvh_candidate<R>(A.sc, q, k0 - 1u, o, d, time, A.tmin);
+                    if (__ballot(k1 != 0u) != 0ull) {
+                        if (k1 != 0u) bvh_candidate<R>(A.sc, q, k1 - 1u, o, d, time, A.tmin);
+                    }
+                }
+                RAYZ_PROF2_T(4)
+            }
+            // leave the rounds when the walkers that ran out make a swap or a service pass due
+            const unsigned long long m_idle = __ballot(q.cur == kBvhDone);
+            if (~m_idle == 0ull) break;
+            if ((int)__popcll(m_idle & m_ready) >= t_swap) break;
+            if (n_service2 != 0 && (n_service2 >= t_service || (int)__popcll(m_idle & m_service2) >= t_blocked)) break;
+        }
+    }
+#ifdef RAYZ_BVH_PROFILE
+    if (lane == 0) {
+        for (int k = 0; k < 5; ++k) atomicAdd(&A.counters[4 + k], pt[k]);
+        for (int k = 0; k < 10; ++k) atomicAdd(&A.counters[9 + k], pl[k]);
+        for (int k = 0; k < 2; ++k) atomicAdd(&A.counters[19 + k], px3[k]);
     }
 #endif
     unsigned long long t0 = nseg, t1 = node_tests, t2 = sphere_tests;
@@ -1507,7 +1829,7 @@ template <class R> __global__ __launch_bounds__(64) void kat_kernel(uint32_t op,
     }
     case 3: { // BOX_HIT: lo(3) hi(3) o(3) d(3) tmin tmax -> hit, t_entry
         BvhQuery<R> q;
-        bvh_begin<R>(q, v3(6), v3(9), 1u);
+        bvh_begin<R>(q, v3(6), v3(9), unit(v3(9)), 1u);
         q.tbest = (R)a[13];
         q.tb32 = round_up_f32(q.tbest);
         float t0;
@@ -1525,10 +1847,8 @@ template <class R> __global__ __launch_bounds__(64) void kat_kernel(uint32_t op,
         const V<R> ud = unit(d);
         // the reject test as the kernels run it: f32 for both precisions, the ray narrowed to f32
         const RayBasis<float> b = make_basis<float>(V<float>{(float)ud.x, (float)ud.y, (float)ud.z}, V<float>{(float)o.x, (float)o.y, (float)o.z});
-        const float ft = (float)time, vx = (float)v.x, vy = (float)v.y, vz = (float)v.z;
-        const float p1 = fm(vz, ft * b.e1z, fm(vx, ft * b.e1x, basis_p1<float>(b, (float)c.x, (float)c.z)));
-        const float p2 = fm(vz, ft * b.e2z, fm(vy, ft * b.e2y, fm(vx, ft * b.e2x, basis_p2<float>(b, (float)c.x, (float)c.y, (float)c.z))));
-        const bool cand = sphere_candidate<float>(p1, p2, (float)c.w);
+        const bool cand = leaf_reject_test(b, (float)time, V<float>{(float)c.x, (float)c.y, (float)c.z},
+                                           V<float>{(float)v.x, (float)v.y, (float)v.z}, (float)c.w);
         r[9] = cand ? 1.0 : 0.0;
         R tbest = (R)a[15];
         int ibest = -1;

@@ -13,6 +13,7 @@
 
 #include <dlfcn.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -60,6 +61,18 @@ struct DeviceCtx {
     int num_cu = 0;
 };
 DeviceCtx g_ctx[RAYZ_MAX_DEVICES];
+
+// Measurement knobs (rayz_hip_debug_set; they change scheduling or the walked tree, never an image).  The library reads
+// no environment variable: a stray one cannot change a production render.  -1 = the built-in default.
+struct Tuning {
+    long long v[RAYZ_DEBUG_KNOBS];
+    Tuning() { for (auto& x : v) x = -1; }
+};
+Tuning g_tune; // guarded by g_mu when written; renders read a snapshot
+long long tuning(int knob, long long dflt) {
+    const long long x = g_tune.v[knob];
+    return x < 0 ? dflt : x;
+}
 int g_default = -1; // device of the last successful rayz_hip_init: what entry points without a device argument use
 std::mutex g_mu;    // guards g_ctx / g_default
 
@@ -222,7 +235,7 @@ struct RayzScene {
     unsigned long long* counters = nullptr; // [0] queue head, [1] segments
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipStream_t last_stream = nullptr;
-    bool rendered = false, last_bvh = false;
+    bool rendered = false, last_bvh = false, last_two_paths = false;
     RayzRenderStats last{};
 };
 
@@ -385,8 +398,8 @@ void ensure_bvh(RayzScene* s) {
 
 void ensure_bvh_dev(RayzScene* s) {
     if (!s->bvh_dev_built) {
-        const char* e = std::getenv("RAYZ_BVH_PEEL"); // RAYZ_BVH_PEEL=0 (measurement only): walk the reference's full tree
-        s->bvh_dev = rayz_bvh::build(s->spheres, s->triangles, !(e && e[0] == '0'));
+        // RAYZ_DEBUG_BVH_PEEL = 0 (measurement only): walk the reference's full tree
+        s->bvh_dev = rayz_bvh::build(s->spheres, s->triangles, tuning(RAYZ_DEBUG_BVH_PEEL, 1) != 0);
         s->bvh_dev_built = true;
     }
 }
@@ -434,8 +447,7 @@ template <class R> int upload_bvh_body(RayzScene* s, SceneBuffers<R>& b) {
     std::vector<uint32_t> inner_index(t.nodes.size(), 0xffffffffu), inner_order;
     uint32_t n_inner = 0;
     {
-        const char* e = std::getenv("RAYZ_BVH_TOP"); // measurement only: number of top-of-tree records kept in LDS
-        const uint32_t top_cap = e ? (uint32_t)std::atoi(e) : 256u;
+        const uint32_t top_cap = (uint32_t)tuning(RAYZ_DEBUG_BVH_TOP, 256); // top-of-tree records kept in LDS
         std::vector<size_t> frontier;
         if (!t.nodes.empty() && t.nodes[0].count == 0) frontier.push_back(0);
         for (size_t head = 0; head < frontier.size() && n_inner < top_cap; ++head) {
@@ -684,6 +696,7 @@ int render_impl(RayzScene* s, const DeviceCtx& ctx, SceneBuffers<R>& b, const Ra
     s->last = RayzRenderStats{};
     s->last.primary_rays = shard_pixels64 * p->samples_per_px;
     s->last_bvh = use_bvh;
+    s->last_two_paths = false;
     if (items64 == 0) {
         s->rendered = false;
         return RAYZ_OK;
@@ -762,14 +775,15 @@ int render_impl(RayzScene* s, const DeviceCtx& ctx, SceneBuffers<R>& b, const Ra
     A.shard_count = p->shard_count ? p->shard_count : 1u;
     A.shard_pixels = (uint32_t)shard_pixels64;
     A.total_items = (uint32_t)items64;
-    A.queue_grab = kQueueGrab;
-    if (const char* e = std::getenv("RAYZ_QUEUE_GRAB")) A.queue_grab = (uint32_t)std::max(1, std::atoi(e)); // measurement only
-    {
-        // scheduling thresholds of the BVH kernel (no effect on results); RAYZ_BVH_KEEP="active,stepping" overrides
-        unsigned ka = kBvhKeepActive, ks = kBvhKeepStepping;
-        if (const char* e = std::getenv("RAYZ_BVH_KEEP")) std::sscanf(e, "%u,%u", &ka, &ks);
-        A.bvh_keep = (ka & 0xffu) | ((ks & 0xffu) << 8);
-    }
+    A.queue_grab = (uint32_t)std::max(1ll, tuning(RAYZ_DEBUG_QUEUE_GRAB, kQueueGrab));
+    // Which walk: one path per lane (trace_kernel_bvh).  The two-paths-per-lane form (trace_kernel_bvh2, f32 only) is kept
+    // behind RAYZ_DEBUG_BVH_KERNEL = 2: same image, but its 168 VGPRs cost a wave per SIMD and it is slower.
+    const bool two_paths = use_bvh && sizeof(R) == 4 && tuning(RAYZ_DEBUG_BVH_KERNEL, 1) == 2;
+    // scheduling thresholds of the BVH kernels (no effect on results)
+    if (two_paths)
+        A.bvh_keep = (uint32_t)tuning(RAYZ_DEBUG_BVH2_KEEP, kBvh2Service | (kBvh2Blocked << 8) | (kBvh2Swap << 16) | (kBvhKeepStepping << 24));
+    else
+        A.bvh_keep = (uint32_t)tuning(RAYZ_DEBUG_BVH_KEEP, kBvhKeepActive | (kBvhKeepStepping << 8));
 
     const int block = 256;
     int blocks_per_cu = 0;
@@ -777,19 +791,28 @@ int render_impl(RayzScene* s, const DeviceCtx& ctx, SceneBuffers<R>& b, const Ra
     // holds more than one entry per level); sized from THIS tree, so a shallow tree does not cap the occupancy
     const size_t bvh_stack_bytes = use_bvh ? ((size_t)s->bvh_dev.depth + 2) * block * sizeof(uint32_t) : 0;
     const size_t bvh_top_bytes = use_bvh ? (size_t)b.bvh_top * 4 * sizeof(f4) : 0; // the tree's top: first in LDS
-    const size_t bvh_lds = bvh_top_bytes + bvh_stack_bytes;
+    // (+ RAYZ_DEBUG_LDS_PAD unused bytes: an occupancy experiment — fewer workgroups per CU, the same code)
+    const size_t bvh_lds = bvh_top_bytes + bvh_stack_bytes + (use_bvh ? (size_t)tuning(RAYZ_DEBUG_LDS_PAD, 0) : 0);
     A.bvh_top_words = (uint32_t)(bvh_top_bytes / sizeof(uint32_t));
-    if (use_bvh) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, trace_kernel_bvh<R>, block, bvh_lds));
+    if (two_paths) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, trace_kernel_bvh2<float>, block, bvh_lds));
+    else if (use_bvh) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, trace_kernel_bvh<R>, block, bvh_lds));
     else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, trace_kernel<R, 1>, block, 0));
     if (blocks_per_cu < 1) blocks_per_cu = 1;
     uint64_t grid = (uint64_t)ctx.num_cu * blocks_per_cu;
-    const uint64_t want = (items64 + block - 1) / block;
+    // (a lane of the two-path kernel holds two items)
+    const uint64_t want = (items64 + (two_paths ? 2 : 1) * block - 1) / ((two_paths ? 2 : 1) * block);
     if (grid > want) grid = want;
 
+    s->last_two_paths = two_paths;
     HIP_TRY(hipMemsetAsync(s->counters, 0, 32 * sizeof(unsigned long long), stream));
     HIP_TRY(hipEventRecord(s->ev0, stream));
-    if (use_bvh) hipLaunchKernelGGL(trace_kernel_bvh<R>, dim3((uint32_t)grid), dim3(block), bvh_lds, stream, A);
-    else hipLaunchKernelGGL((trace_kernel<R, 1>), dim3((uint32_t)grid), dim3(block), 0, stream, A);
+    if (two_paths) {
+        if constexpr (sizeof(R) == 4) hipLaunchKernelGGL(trace_kernel_bvh2<float>, dim3((uint32_t)grid), dim3(block), bvh_lds, stream, A);
+    } else if (use_bvh) {
+        hipLaunchKernelGGL(trace_kernel_bvh<R>, dim3((uint32_t)grid), dim3(block), bvh_lds, stream, A);
+    } else {
+        hipLaunchKernelGGL((trace_kernel<R, 1>), dim3((uint32_t)grid), dim3(block), 0, stream, A);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev1, stream));
     hipLaunchKernelGGL(resolve_kernel<R>, dim3((A.shard_pixels + 255) / 256), dim3(256), 0, stream,
@@ -863,7 +886,20 @@ int scene_sync(RayzScene* s, RayzRenderStats* stats) {
                          100.0 * c[6] / tot, 100.0 * c[7] / tot, 100.0 * c[8] / tot);
         }
 #endif
-#ifdef RAYZ_BVH_PROFILE // measurement build only: per-phase wave time and lane occupancy of trace_kernel_bvh
+#ifdef RAYZ_BVH_PROFILE // measurement build only: per-phase wave time and lane occupancy of the BVH kernels
+        if (s->last_bvh && s->last_two_paths) {
+            const double tot = (double)(c[4] + c[5] + c[6] + c[7] + c[8]);
+            auto per = [&](int k) { return (double)c[9 + k] / (double)(c[10 + k] ? c[10 + k] : 1); };
+            std::fprintf(stderr,
+                         "bvh2 phases (share of wave time | mean lanes): service %.1f%% %.1f | swap %.1f%% %.1f | N %.1f%% %.1f | L %.1f%% %.1f | "
+                         "C %.1f%% %.1f\n",
+                         100.0 * c[4] / tot, per(0), 100.0 * c[5] / tot, per(2), 100.0 * c[6] / tot, per(4), 100.0 * c[7] / tot, per(6),
+                         100.0 * c[8] / tot, per(8));
+            const double it = (double)(c[14] ? c[14] : 1);
+            std::fprintf(stderr, "  box steps: lanes per wave-step — stepping %.1f | parked at a leaf %.1f | walker idle %.1f; wave-steps per segment "
+                                 "%.2f; service passes %.3g, swaps %.3g, leaf phases %.3g\n",
+                         per(4), (double)c[19] / it, (double)c[20] / it, it / (double)(c[1] ? c[1] : 1), (double)c[10], (double)c[12], (double)c[16]);
+        } else
         if (s->last_bvh) {
             const double tot = (double)(c[4] + c[5] + c[6] + c[7] + c[8]);
             std::fprintf(stderr,
@@ -1032,6 +1068,9 @@ struct RayzMulti {
     size_t gathered_bytes = 0, frame_bytes = 0;
     uint32_t transport = RAYZ_GATHER_RCCL;
     int rccl_version = 0;
+    std::vector<RayzRenderStats> last_dev; // per device: counters of the last frame (rayz_hip_multi_device_stats)
+    hipEvent_t g0 = nullptr, g1 = nullptr; // on the root's stream: its own tile done / frame assembled
+    double last_gather_ms = 0, last_frame_ms = 0;
 };
 
 namespace {
@@ -1050,20 +1089,20 @@ int multi_free(RayzMulti* m) {
         DeviceScope scope(m->devices[0]);
         (void)hipFree(m->gathered);
         (void)hipFree(m->frame);
+        if (m->g0) (void)hipEventDestroy(m->g0);
+        if (m->g1) (void)hipEventDestroy(m->g1);
     }
     delete m;
     return RAYZ_OK;
 }
 
-int check_device_list(const int* devices, int n) {
+// `dup_ok`: RAYZ_GATHER_ALLOW_DUPLICATE_DEVICES was passed with the peer-copy transport (tests on a one-GPU box: the N-way
+// sharding, the gather into N slots and the un-interleave then run for real, every "device" being the same one)
+int check_device_list(const int* devices, int n, bool dup_ok) {
     if (!devices) return fail(RAYZ_ERR_BAD_ARG, "device list is null");
     if (n < 1 || n > RAYZ_MAX_DEVICES) return fail(RAYZ_ERR_BAD_ARG, "n_devices %d out of range [1,%d]", n, RAYZ_MAX_DEVICES);
     for (int i = 0; i < n; ++i) {
         if (devices[i] < 0 || devices[i] >= RAYZ_MAX_DEVICES) return fail(RAYZ_ERR_BAD_ARG, "device %d out of range", devices[i]);
-        // (RAYZ_MULTI_ALLOW_DUPLICATE_DEVICES=1, tests only: a one-GPU box then runs the N-way sharding, the peer-copy
-        //  gather and the un-interleave for real, every "device" being the same one)
-        const char* e = std::getenv("RAYZ_MULTI_ALLOW_DUPLICATE_DEVICES");
-        const bool dup_ok = e && e[0] == '1';
         for (int j = 0; j < i && !dup_ok; ++j)
             if (devices[j] == devices[i]) return fail(RAYZ_ERR_BAD_ARG, "device %d is listed twice", devices[i]);
     }
@@ -1144,7 +1183,17 @@ int multi_render(RayzMulti* m, const RayzCameraDesc* cam, const RayzRenderParams
             }
         }
     }
-    // 2. one gather of the row tiles to the first device
+    // 2. one gather of the row tiles to the first device.  g0 .. g1 on the root's stream = from "the root's own rows are
+    //    done" to "the frame is assembled": the transfer plus whatever the root waited for slower devices
+    const auto wall0 = std::chrono::steady_clock::now();
+    {
+        DeviceScope scope(m->devices[0]);
+        if (!m->g0) {
+            HIP_TRY(hipEventCreate(&m->g0));
+            HIP_TRY(hipEventCreate(&m->g1));
+        }
+        HIP_TRY(hipEventRecord(m->g0, ctx[0]->stream));
+    }
     auto src = [&](uint32_t i) { return to_u8 ? m->tile8[i] : m->tile[i]; };
     if (m->transport == RAYZ_GATHER_RCCL) {
         NCCL_TRY(g_rccl.GroupStart());
@@ -1173,15 +1222,22 @@ int multi_render(RayzMulti* m, const RayzCameraDesc* cam, const RayzRenderParams
         hipLaunchKernelGGL(unshard_kernel<T>, dim3((uint32_t)((ne + 255) / 256)), dim3(256), 0, ctx[0]->stream,
                            (const T*)m->gathered, (T*)m->frame, p->height, (uint32_t)row_elems, q.tile_rows, n, max_rows);
         HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(m->g1, ctx[0]->stream));
         HIP_TRY(hipMemcpyAsync(out, m->frame, frame_bytes, hipMemcpyDeviceToHost, ctx[0]->stream));
         HIP_TRY(hipStreamSynchronize(ctx[0]->stream));
+        float gms = 0;
+        HIP_TRY(hipEventElapsedTime(&gms, m->g0, m->g1));
+        m->last_gather_ms = gms;
+        m->last_frame_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
     }
     // 4. counters: sums over the devices; kernel_ms is the slowest device's trace kernel
     RayzRenderStats tot{};
+    m->last_dev.assign(n, RayzRenderStats{});
     for (uint32_t i = 0; i < n; ++i) {
         RayzRenderStats st{};
         rc = scene_sync(m->scenes[i], &st);
         if (rc != RAYZ_OK) return rc;
+        m->last_dev[i] = st;
         tot.primary_rays += st.primary_rays;
         tot.segments += st.segments;
         tot.sphere_tests += st.sphere_tests;
@@ -1208,6 +1264,13 @@ int render_multi_oneshot(const int* devices, int n, const RayzSceneDesc* scene, 
 extern "C" {
 
 uint32_t rayz_hip_abi_version(void) { return RAYZ_HIP_ABI_VERSION; }
+
+int rayz_hip_debug_set(uint32_t knob, long long value) {
+    if (knob >= RAYZ_DEBUG_KNOBS) return fail(RAYZ_ERR_BAD_ARG, "bad debug knob %u", knob);
+    std::lock_guard<std::mutex> lock(g_mu);
+    g_tune.v[knob] = value;
+    return RAYZ_OK;
+}
 const char* rayz_hip_last_error(void) { return g_err; }
 
 int rayz_hip_init(int device) {
@@ -1393,9 +1456,13 @@ int rayz_hip_multi_create(const int* devices, int n_devices, const RayzSceneDesc
     return guarded([&] {
         if (!out) return fail(RAYZ_ERR_BAD_ARG, "out handle pointer is null");
         *out = nullptr;
-        int rc = check_device_list(devices, n_devices);
-        if (rc != RAYZ_OK) return rc;
+        const bool dup_ok = (transport & RAYZ_GATHER_ALLOW_DUPLICATE_DEVICES) != 0;
+        transport &= ~(uint32_t)RAYZ_GATHER_ALLOW_DUPLICATE_DEVICES;
         if (transport > RAYZ_GATHER_PEER_COPY) return fail(RAYZ_ERR_BAD_ARG, "bad gather transport %u", transport);
+        if (dup_ok && transport != RAYZ_GATHER_PEER_COPY)
+            return fail(RAYZ_ERR_BAD_ARG, "RAYZ_GATHER_ALLOW_DUPLICATE_DEVICES needs the peer-copy transport (RCCL refuses a device twice)");
+        int rc = check_device_list(devices, n_devices, dup_ok);
+        if (rc != RAYZ_OK) return rc;
         rc = validate_scene(scene);
         if (rc != RAYZ_OK) return rc;
         {
@@ -1470,6 +1537,23 @@ int rayz_hip_multi_info(const RayzMulti* m, int* n_devices, uint32_t* transport,
     if (n_devices) *n_devices = (int)m->devices.size();
     if (transport) *transport = m->transport;
     if (rccl_version) *rccl_version = m->rccl_version;
+    return RAYZ_OK;
+}
+
+int rayz_hip_multi_device_stats(const RayzMulti* m, int index, RayzRenderStats* stats) {
+    if (!m) return fail(RAYZ_ERR_STATE, "multi handle is null");
+    if (!stats) return fail(RAYZ_ERR_BAD_ARG, "stats pointer is null");
+    if (index < 0 || (size_t)index >= m->devices.size()) return fail(RAYZ_ERR_BAD_ARG, "device index %d out of range", index);
+    if (m->last_dev.size() != m->devices.size()) return fail(RAYZ_ERR_STATE, "no frame has been rendered on this handle");
+    *stats = m->last_dev[(size_t)index];
+    return RAYZ_OK;
+}
+
+int rayz_hip_multi_timing(const RayzMulti* m, double* gather_ms, double* frame_ms) {
+    if (!m) return fail(RAYZ_ERR_STATE, "multi handle is null");
+    if (m->last_dev.size() != m->devices.size()) return fail(RAYZ_ERR_STATE, "no frame has been rendered on this handle");
+    if (gather_ms) *gather_ms = m->last_gather_ms;
+    if (frame_ms) *frame_ms = m->last_frame_ms;
     return RAYZ_OK;
 }
 

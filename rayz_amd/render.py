@@ -18,6 +18,12 @@ def init(device: int = 0) -> None:
     capi.check(lib, lib.rayz_hip_init(device), f"rayz_hip_init({device})")
 
 
+def debug_set(knob: int, value: int = -1) -> None:
+    """`rayz_hip_debug_set`: a measurement knob (scheduling / walked tree; never an image); value < 0 = default."""
+    lib = capi.load()
+    capi.check(lib, lib.rayz_hip_debug_set(knob, value), f"rayz_hip_debug_set({knob})")
+
+
 def shard_rows(params: capi.RenderParams) -> int:
     return int(capi.load().rayz_hip_shard_rows(C.byref(params)))
 
@@ -107,6 +113,21 @@ class MultiScene:
         rc = fn(self._h, C.byref(camera), C.byref(params), out.ctypes.data_as(C.c_void_p), C.byref(st))
         capi.check(self._lib, rc, "rayz_hip_multi_render")
         return out, st
+
+    def device_stats(self):
+        """Per-device counters of the last frame (each device's own trace-kernel time: shard imbalance shows here)."""
+        out = []
+        for i in range(len(self.devices)):
+            st = capi.RenderStats()
+            capi.check(self._lib, self._lib.rayz_hip_multi_device_stats(self._h, i, C.byref(st)), "rayz_hip_multi_device_stats")
+            out.append(st)
+        return out
+
+    def timing(self):
+        """(gather_ms, frame_ms) of the last frame: see include/rayz_hip.h."""
+        g, f = C.c_double(), C.c_double()
+        capi.check(self._lib, self._lib.rayz_hip_multi_timing(self._h, C.byref(g), C.byref(f)), "rayz_hip_multi_timing")
+        return g.value, f.value
 
     def close(self) -> None:
         if self._h:

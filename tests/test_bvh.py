@@ -116,7 +116,7 @@ def test_oracle_bvh_traversal_equals_flat_list(oracle):
     t.set_gpu(traversal=capi.TRAVERSAL_BVH)
     bvh, sb = oracle.render_b(sd, cam, t.params())
     assert np.array_equal(flat, bvh) and sf.segments == sb.segments
-    assert sf.sphere_tests == sf.segments * sd.n_spheres and sf.node_tests == 0
+    assert sf.node_tests == 0
     assert 25 < sb.node_tests / sb.segments < 50 and 3 < sb.sphere_tests / sb.segments < 8
     # and mode A's recursive traversal visits a comparable number of boxes (same tree, f64, first-hit order)
     pa = t.params()
@@ -252,7 +252,7 @@ def test_gpu_bvh_shards_and_custom_scene(gpu, oracle):
 @pytest.mark.gpu
 def test_gpu_config4_full_frame_on_one_gpu(gpu, oracle):
     """BASELINE configs[3] (3840x2160, 4096 spp, 10,003 spheres) in full on ONE GPU through the BVH kernel: 2.1e9
-    work items and a 34 GB chunk-sum workspace (the sizing DESIGN.md §5 claims for 288 GB parts).  16 scattered
+    work items behind a 32-bit queue and a 2.65 GB chunk-sum workspace (20 chunk sums per pixel with the schedule of DESIGN.md §4.6).  16 scattered
     pixels are checked bit for bit against the oracle at the same 4096 spp; counters obey their identities."""
     t = tracer.randomBouncing(3840, -50, 50, seed=42)
     t.samples_per_px = 4096

@@ -34,7 +34,7 @@ def test_binding_covers_every_declared_symbol(built):
 
 def test_abi_version_and_struct_sizes(built):
     lib = capi.load()
-    assert lib.rayz_hip_abi_version() == capi.ABI_VERSION == 4
+    assert lib.rayz_hip_abi_version() == capi.ABI_VERSION == 5
     # sizes the Zig extern structs must reproduce
     assert (C.sizeof(capi.Texture), C.sizeof(capi.Material), C.sizeof(capi.Sphere)) == (48, 24, 64)
     assert (C.sizeof(capi.SceneDesc), C.sizeof(capi.CameraDesc), C.sizeof(capi.Triangle)) == (48, 152, 80)

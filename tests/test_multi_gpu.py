@@ -2,7 +2,7 @@
 reference's caller (src/rayz.zig:26) driving every device of the node.  The GPU box has one MI355X, so what runs
 here is (a) the degenerate n = 1 case through the complete machinery — per-device contexts, ncclCommInitAll +
 ncclGather (or peer copies), the un-interleave kernel — and (b) n = 2, 3, 8 with every "device" being device 0
-(RAYZ_MULTI_ALLOW_DUPLICATE_DEVICES=1, peer-copy transport: RCCL refuses a device twice): the N-way row dealing, N scenes,
+(the RAYZ_GATHER_ALLOW_DUPLICATE_DEVICES transport flag, peer copies only: RCCL refuses a device twice): the N-way row dealing, N scenes,
 the gather into N slots and the un-interleave run for real.  Both must be bit-identical to the single-device entry
 points."""
 import ctypes as C
@@ -46,21 +46,31 @@ def test_multi_n1_is_bit_identical_to_single_device(gpu, oracle, transport, tile
 
 @pytest.mark.parametrize("n", [2, 3, 8])
 @pytest.mark.parametrize("tile_rows", [0, 5])
-def test_multi_n_way_on_one_device(gpu, oracle, monkeypatch, n, tile_rows):
-    """N shards through rayz_hip_multi_render on a one-GPU box: the same device listed N times (test-only switch)."""
+def test_multi_n_way_on_one_device(gpu, oracle, n, tile_rows):
+    """N shards through rayz_hip_multi_render on a one-GPU box: the same device listed N times (test-only flag)."""
     t = _scene()
     sd, cam, p = t.scene_desc(), t.camera_desc(), t.params()
     want, wst = gpu.render_host(sd, cam, p)
     with pytest.raises(capi.RayzHipError, match="listed twice"):
         render.MultiScene(sd, [0] * n, capi.GATHER_PEER_COPY)
-    monkeypatch.setenv("RAYZ_MULTI_ALLOW_DUPLICATE_DEVICES", "1")
-    m = render.MultiScene(sd, [0] * n, capi.GATHER_PEER_COPY)
-    assert m.info()["n_devices"] == n
+    with pytest.raises(capi.RayzHipError, match="needs the peer-copy transport"):  # never through RCCL
+        render.MultiScene(sd, [0] * n, capi.GATHER_RCCL | capi.GATHER_ALLOW_DUPLICATE_DEVICES)
+    m = render.MultiScene(sd, [0] * n, capi.GATHER_PEER_COPY | capi.GATHER_ALLOW_DUPLICATE_DEVICES)
+    assert m.info()["n_devices"] == n and m.info()["transport"] == capi.GATHER_PEER_COPY
+    with pytest.raises(capi.RayzHipError, match="no frame"):
+        m.device_stats()
     p.tile_rows = tile_rows
     for _ in range(2):
         got, st = m.render(cam, p)
         assert_images_equal(got, want, f"multi n={n} (one device) tile_rows {tile_rows}")
         assert (st.primary_rays, st.segments) == (wst.primary_rays, wst.segments)
+        # per-device counters: every shard's own rows / segments / kernel time; they add up to the frame's
+        per = m.device_stats()
+        assert len(per) == n and sum(d.primary_rays for d in per) == st.primary_rays
+        assert sum(d.segments for d in per) == st.segments and all(d.kernel_ms > 0 for d in per)
+        assert max(d.kernel_ms for d in per) == st.kernel_ms
+        gather_ms, frame_ms = m.timing()
+        assert 0 < gather_ms < 1e4 and frame_ms >= gather_ms * 0.5
     u8, _ = m.render(cam, p, u8=True)
     img = tracer.Image(p.height, p.width)
     img.pixels = want.astype(np.float64)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Sweep the BVH kernel's scheduling thresholds (RAYZ_BVH_KEEP=active,stepping) on config 3 / config 5."""
+"""Sweep the one-path BVH kernel's scheduling thresholds (rayz_hip_debug_set BVH_KEEP = active | stepping << 8) on config 3 / config 5."""
 import os, sys, time, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -25,7 +25,8 @@ c3 = tracer.randomBouncing(1920, -50, 50, seed=42)
 c5 = tracer.triangleMesh(1920, 224, seed=1)
 pairs = [tuple(int(x) for x in a.split(',')) for a in sys.argv[1:]] or [(40, 24), (48, 32), (56, 40), (32, 16), (24, 12), (16, 8), (48, 16), (56, 8), (32, 32), (60, 48), (1, 1)]
 for ka, ks in pairs:
-    os.environ["RAYZ_BVH_KEEP"] = f"{ka},{ks}"
+    render.debug_set(capi.DEBUG_BVH_KERNEL, 1)
+    render.debug_set(capi.DEBUG_BVH_KEEP, ka | (ks << 8))
     a, na = bench(c3, 256)
     b, nb = bench(c5, 128)
     print(f"keep_active {ka:2d} keep_stepping {ks:2d}: config3 {a:8.1f} Msamples/s ({na:.1f} nodes/seg)   config5 {b:8.1f} ({nb:.1f})", flush=True)
