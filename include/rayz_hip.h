@@ -301,7 +301,10 @@ int rayz_hip_tonemap_u8(const float* d_rgb, uint8_t* d_rgb8, size_t n_pixels, vo
 /* ---- known answers ---------------------------------------------------------------------------------------------
  * Evaluates the trace kernels' OWN device functions (the same inlined code the kernels run) on caller inputs, one
  * GPU thread per record, so that the reference's test vectors and a CPU restatement can be held against the
- * device code directly: src/material.zig:213-223 (refract), src/renderer.zig:129-149 (get ray),
+ * device code directly.  Covered: everything a path is assembled from, the BVH kernels' leaf reject test
+ * (leaf_reject_test, shared with the walk) included.  NOT covered: the flat list's packed-FMA form of that test
+ * (ScanGroup::discs, two spheres per v_pk_fma_f32 off scalar registers) — it has no per-record form; whole-frame
+ * renders hold it to the oracle bit for bit instead (tests/test_gpu_parity.py).  Vectors: src/material.zig:213-223 (refract), src/renderer.zig:129-149 (get ray),
  * src/hit.zig:247-279 (bbox hit); tests/test_kat_gpu.py.  Host buffers: `in` = n records of RAYZ_KAT_IN_STRIDE
  * doubles, `out` = n records of RAYZ_KAT_OUT_STRIDE doubles (unused slots 0).  Values are narrowed to `precision`
  * as a scene is when it crosses the ABI.  Random draws, where an op makes any, come from the record's list u[]
@@ -310,7 +313,8 @@ typedef enum RayzKatOp {
     RAYZ_KAT_REFRACT = 0,     /* in: unit_dir[0..2] normal[3..5] eta[6]            out: dir[0..2]       src/material.zig:189-194 */
     RAYZ_KAT_REFLECTANCE = 1, /* in: cos[0] ri[1]                                  out: r[0]            src/material.zig:179-183 */
     RAYZ_KAT_GET_RAY = 2,     /* in: look_from px_du px_dv px_origin defocus_u defocus_v [0..17] defocus[18] px[19] py[20]
-                                     n_u[21] u[22..]; n_u = 0 is NOT getRay(px,py,null): the kernel always draws
+                                     n_u[21] (an integer in [0, 26], RAYZ_ERR_BAD_ARG otherwise) u[22..]; n_u = 0 is NOT
+                                     getRay(px,py,null): the kernel always draws
                                  out: origin[0..2] dir[3..5] time[6] draws[7]                           src/camera.zig:59-90 */
     RAYZ_KAT_BOX_HIT = 3,     /* in: low[0..2] high[3..5] origin[6..8] dir[9..11] tmin[12] tmax[13]
                                  out: hit[0] t_entry[1]                                                 src/hit.zig:70-98 */
@@ -318,7 +322,7 @@ typedef enum RayzKatOp {
                                  out: hit[0] t[1] point[2..4] normal[5..7] front_face[8] passed_filter[9]
                                                                                         src/geom.zig:38-66, src/hit.zig:25-41 */
     RAYZ_KAT_SCATTER = 5,     /* in: kind[0] method[1] param[2] ray origin[3..5] dir[6..8] hit point[9..11] normal[12..14]
-                                     front_face[15] n_u[16] u[17..]
+                                     front_face[15] n_u[16] (an integer in [0, 31]) u[17..]
                                  out: scattered[0] dir[1..3] draws[4]                                   src/material.zig:73-160 */
     RAYZ_KAT_CHECKER = 6,     /* in: point[0..2] scale[3]                          out: parity[0]       src/material.zig:32-36 */
     RAYZ_KAT_BACKGROUND = 7,  /* in: dir[0..2]                                     out: colour[0..2]    src/renderer.zig:124-125 */

@@ -1235,6 +1235,12 @@ static int render(const RayzSceneDesc* sd, const RayzCameraDesc* cd, const RayzR
     if (!sd || !cd || !pp || !out) return RAYZ_ERR_BAD_ARG;
     const RayzRenderParams p = *pp;
     if (!p.width || !p.height || !p.samples_per_px) return RAYZ_ERR_BAD_ARG;
+    {   // the library refuses schedules of 2^20 chunks per pixel or more, whatever chunk_spp is (0 = automatic included)
+        const u64 spp = p.samples_per_px;
+        const bool uniform = p.chunk_spp != 0 || (u64)p.width * p.height < (1ull << 19) || spp < 64;
+        const u64 c = p.chunk_spp ? p.chunk_spp : 16;
+        if ((uniform ? (spp + c - 1) / c : spp / 256 + 8) >= (1ull << 20)) return RAYZ_ERR_BAD_ARG;
+    }
     SceneB<R> sc = buildScene<R>(*sd, originBound(*sd, cd));
     if (useBvh(*pp, sd->n_spheres + sd->n_triangles)) buildBvh<R>(*sd, sc);
     const CamB<R> cam = buildCamera<R>(*cd);

@@ -123,6 +123,17 @@ inline FlatBvh build(const std::vector<RayzSphere>& spheres, const std::vector<R
         h[spheres.size() + i] = {triangleBox(triangles[i]), (uint32_t)(spheres.size() + i)};
     if (peel_oversized) {
         auto extent = [](const Box& b) { return std::fmax(std::fmax(b.hi[0] - b.lo[0], b.hi[1] - b.lo[1]), b.hi[2] - b.lo[2]); };
+        // an OUTLIER only: longer than a quarter of everything else AND more than kOutlier times the median hittable — a
+        // compact cluster of similar hittables, each spanning a good part of the cluster, stays whole (it would be
+        // tested once per segment, f64 roots included, ahead of a walk that could have culled it)
+        constexpr double kOutlier = 8.0;
+        double median = 0;
+        {
+            std::vector<double> ext(h.size());
+            for (size_t i = 0; i < h.size(); ++i) ext[i] = extent(h[i].box);
+            std::nth_element(ext.begin(), ext.begin() + (ptrdiff_t)(ext.size() / 2), ext.end());
+            median = ext[ext.size() / 2];
+        }
         while (out.big.size() < kMaxBig && h.size() > kMinTree) {
             size_t worst = 0;
             for (size_t i = 1; i < h.size(); ++i)
@@ -130,7 +141,7 @@ inline FlatBvh build(const std::vector<RayzSphere>& spheres, const std::vector<R
             Box rest;
             for (size_t i = 0; i < h.size(); ++i)
                 if (i != worst) rest.enclose(h[i].box);
-            if (!(extent(h[worst].box) > 0.25 * extent(rest))) break;
+            if (!(extent(h[worst].box) > 0.25 * extent(rest) && extent(h[worst].box) > kOutlier * median)) break;
             out.big.push_back(h[worst].pool);
             h.erase(h.begin() + (ptrdiff_t)worst); // keeps pool order among the rest
         }

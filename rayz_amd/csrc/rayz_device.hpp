@@ -1007,6 +1007,12 @@ __device__ __forceinline__ float max_bound(float x, float bound) {
     asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(bound));
     return r;
 }
+// .. the same with a WAVE-UNIFORM bound read straight from a scalar register (as a "v" operand the loop pays a v_mov per step)
+__device__ __forceinline__ float max_bound_uniform(float x, float bound) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "s"(bound), "v"(x));
+    return r;
+}
 __device__ __forceinline__ float min_bound(float x, float bound) {
     float r;
     asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(bound));
@@ -1092,14 +1098,15 @@ template <class R> __device__ __forceinline__ void bvh_begin(BvhQuery<R>& q, V<R
 // relative and the absolute slack (BoxSlack).  A direction component of 0 reaches here as ±1/K (bvh_begin): the axis
 // yields huge finite distances of the right sign — the whole line when o lies in the slab, nothing when it lies outside.
 // `tmin` is the caller's tmin rounded DOWN to f32, q.tb32 tbest rounded UP.  Returns the entry distance through `t0`.
-template <class R>
+template <class R, bool kUniformTmin = false>
 __device__ __forceinline__ bool bvh_box_hit(f4 lo, f4 hi, const BvhQuery<R>& q, float tmin, float& t0) {
     const float ax = fm(lo.x, q.inv.x, q.noi.x), bx = fm(hi.x, q.inv.x, q.noi.x);
     const float ay = fm(lo.y, q.inv.y, q.noi.y), by = fm(hi.y, q.inv.y, q.noi.y);
     const float az = fm(lo.z, q.inv.z, q.noi.z), bz = fm(hi.z, q.inv.z, q.noi.z);
     // (tmin and tbest are never NaN: max_bound / min_bound spare the canonicalising copy fmax / fmin would put in front of
     // every use — two vector instructions per step)
-    t0 = mx(mx(mn(ax, bx), mn(ay, by)), max_bound(mn(az, bz), tmin));
+    // (kUniformTmin: the trace kernels' tmin is the launch's, the same for every lane; the known-answer kernel's is per record)
+    t0 = mx(mx(mn(ax, bx), mn(ay, by)), kUniformTmin ? max_bound_uniform(mn(az, bz), tmin) : max_bound(mn(az, bz), tmin));
     float tb;
     if constexpr (sizeof(R) == 4) tb = q.tbest; else tb = q.tb32; // (f32: tbest itself — no second register)
     const float t1 = mn(mn(mx(ax, bx), mx(ay, by)), min_bound(mx(az, bz), tb));
@@ -1154,7 +1161,7 @@ __device__ __forceinline__ void bvh_node_step(const DevScene<R>& sc, const f4* n
     g_fetch_ticks += __builtin_amdgcn_s_memtime() - tl0;
 #endif
     float tl, tr;
-    const bool hl = bvh_box_hit<R>(llo, lhi, q, tmin, tl), hr = bvh_box_hit<R>(rlo, rhi, q, tmin, tr);
+    const bool hl = bvh_box_hit<R, true>(llo, lhi, q, tmin, tl), hr = bvh_box_hit<R, true>(rlo, rhi, q, tmin, tr);
     // Which child was hit decides everything below, so the decisions live as WAVE MASKS in scalar registers (the boolean
     // algebra runs on the scalar unit, which has slack; the vector unit, which has none, spends one v_cndmask per choice):
     const unsigned long long ml = __ballot(hl), mr = __ballot(hr), mlt = __ballot(tr < tl);

@@ -191,6 +191,19 @@ void chunk_schedule(const RayzRenderParams* p, std::vector<uint32_t>& starts) {
     if (rem) starts.push_back(at + rem);
 }
 
+// Number of chunks of that schedule, without building it (a pixel may have at most kMaxChunksPerPx: the table is a host
+// vector, a device array and the divisor of every work item's index).
+constexpr uint64_t kMaxChunksPerPx = 1ull << 20;
+uint64_t chunk_count(const RayzRenderParams* p) {
+    const uint64_t spp = p->samples_per_px;
+    const bool uniform = p->chunk_spp != 0 || (uint64_t)p->width * p->height < (1ull << 19) || spp < 64;
+    if (uniform) {
+        const uint64_t c = p->chunk_spp ? p->chunk_spp : 16u;
+        return (spp + c - 1) / c;
+    }
+    return spp / 256 + 8; // chunks of 256 (or fewer, larger-than-needed bound for spp < 512) + the halving tail
+}
+
 double norm3(const double* v) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
 
 // ---- conservative reject filter ---------------------------------------------------------------
@@ -613,8 +626,8 @@ int validate_params(const RayzRenderParams* p) {
     const uint32_t sc = p->shard_count ? p->shard_count : 1;
     if (p->shard_index >= sc) return fail(RAYZ_ERR_BAD_ARG, "shard_index %u >= shard_count %u", p->shard_index, sc);
     if (!(p->tmin == p->tmin)) return fail(RAYZ_ERR_BAD_ARG, "tmin is NaN");
-    if (p->chunk_spp && (p->samples_per_px - 1) / p->chunk_spp >= (1u << 20))
-        return fail(RAYZ_ERR_BAD_ARG, "more than 2^20 chunks per pixel: raise chunk_spp");
+    if (chunk_count(p) >= kMaxChunksPerPx) // whatever chunk_spp is, 0 (the automatic schedule) included
+        return fail(RAYZ_ERR_BAD_ARG, "more than 2^20 chunks per pixel (%llu): raise chunk_spp", (unsigned long long)chunk_count(p));
     return RAYZ_OK;
 }
 
@@ -1309,6 +1322,7 @@ uint32_t rayz_hip_shard_rows(const RayzRenderParams* p) {
 
 uint32_t rayz_hip_chunk_schedule(const RayzRenderParams* p, uint32_t* starts, uint32_t capacity) {
     if (!p || !p->samples_per_px || !p->width || !p->height) return 0;
+    if (chunk_count(p) >= kMaxChunksPerPx) return 0; // a schedule no render accepts (validate_params)
     std::vector<uint32_t> v;
     try {
         chunk_schedule(p, v);
@@ -1423,6 +1437,13 @@ int rayz_hip_kat(uint32_t op, uint32_t precision, const double* in, uint32_t n, 
         std::vector<double> host(in, in + (size_t)n * RAYZ_KAT_IN_STRIDE);
         for (uint32_t i = 0; i < n; ++i) { // what the scene upload would have prepared for these hittables
             double* a = host.data() + (size_t)i * RAYZ_KAT_IN_STRIDE;
+            // the list of uniforms must lie inside the record: the device reads u[0 .. n_u)
+            if (op == RAYZ_KAT_GET_RAY || op == RAYZ_KAT_SCATTER) {
+                const int at = op == RAYZ_KAT_GET_RAY ? 21 : 16;
+                const double nu = a[at];
+                if (!(nu >= 0 && nu <= RAYZ_KAT_IN_STRIDE - (at + 1) && nu == std::floor(nu)))
+                    return fail(RAYZ_ERR_BAD_ARG, "record %u: n_u = %g is not an integer in [0, %d]", i, nu, RAYZ_KAT_IN_STRIDE - (at + 1));
+            }
             if (op == RAYZ_KAT_SPHERE_HIT) {
                 RayzSphere q{};
                 for (int k = 0; k < 3; ++k) q.center[k] = a[k], q.velocity[k] = a[3 + k];

@@ -13,6 +13,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <random>
 #include <stdexcept>
 #include <string>
@@ -321,7 +322,7 @@ struct GpuOptions {
     uint64_t render_seed = 0; // else drawn from `rng` when render() starts
     uint32_t chunk_spp = 0;
     uint32_t tile_rows = 0, shard_index = 0, shard_count = 0;
-    std::vector<int> devices; // empty: the default device; else render() drives all of these (rayz_hip_render_multi)
+    std::vector<int> devices; // empty: the default device; else render() drives all of these (one kept RayzMulti, rayz_hip_multi_render)
 };
 
 static const double ASPECT_RATIO = 16.0 / 9.0; // src/renderer.zig:16
@@ -336,6 +337,18 @@ struct Tracer {
     MemPool pool;
     GpuOptions gpu;
     RayzRenderStats stats{};
+    // Several GPUs (gpu.devices): the per-device scenes and the RCCL communicators (`ncclCommInitAll`: tens of
+    // milliseconds per device) are kept across render() calls and rebuilt only when the pool or the device list changes,
+    // instead of paying rayz_hip_render_multi's create + destroy per frame.  Shared by copies of the Tracer.
+    struct MultiCache {
+        RayzMulti* handle = nullptr;
+        std::vector<int> devices;
+        std::vector<unsigned char> pool_bytes; // the flattened pool the handle was created from
+        ~MultiCache() {
+            if (handle) rayz_hip_multi_destroy(handle);
+        }
+    };
+    std::shared_ptr<MultiCache> multi_cache;
 
     // `seed` == nullptr seeds from the OS as the reference does (std.posix.getrandom, :55-59)
     static Tracer init(size_t img_w, double vfov, double focus_dist, double defocus_angle, V3 look_from, V3 look_at,
@@ -433,19 +446,37 @@ struct Tracer {
         RayzRenderParams p = params(seed);
         p.shard_index = 0, p.shard_count = 1; // a Tracer owns a whole image
         const size_t n = img.h * img.w;
-        int rc;
+        int rc = RAYZ_OK;
         const bool multi = !gpu.devices.empty();
-        if (multi) p.shard_count = 0; // the library deals the rows to gpu.devices itself
+        RayzMulti* mh = nullptr;
+        if (multi) {
+            p.shard_count = 0; // the library deals the rows to gpu.devices itself
+            std::vector<unsigned char> bytes; // what the pool looks like across the ABI (the reference may edit it between renders)
+            auto append = [&](const void* q, size_t nbytes) { bytes.insert(bytes.end(), (const unsigned char*)q, (const unsigned char*)q + nbytes); };
+            append(f.spheres.data(), f.spheres.size() * sizeof(RayzSphere));
+            append(f.materials.data(), f.materials.size() * sizeof(RayzMaterial));
+            append(f.textures.data(), f.textures.size() * sizeof(RayzTexture));
+            append(f.triangles.data(), f.triangles.size() * sizeof(RayzTriangle));
+            if (!multi_cache) multi_cache = std::make_shared<MultiCache>();
+            MultiCache& mc = *multi_cache;
+            if (!mc.handle || mc.devices != gpu.devices || mc.pool_bytes != bytes) {
+                if (mc.handle) rayz_hip_multi_destroy(mc.handle);
+                mc.handle = nullptr;
+                rc = rayz_hip_multi_create(gpu.devices.data(), (int)gpu.devices.size(), &sd, RAYZ_GATHER_RCCL, &mc.handle);
+                if (rc != RAYZ_OK) throw GpuRenderFailed(rc, rayz_hip_last_error());
+                mc.devices = gpu.devices;
+                mc.pool_bytes.swap(bytes);
+            }
+            mh = mc.handle;
+        }
         if (gpu.precision == RAYZ_PRECISION_F32) {
             std::vector<float> rgb(n * 3);
-            rc = multi ? rayz_hip_render_multi(gpu.devices.data(), (int)gpu.devices.size(), &sd, &cd, &p, rgb.data(), &stats)
-                       : rayz_hip_render(&sd, &cd, &p, rgb.data(), &stats);
+            rc = multi ? rayz_hip_multi_render(mh, &cd, &p, rgb.data(), &stats) : rayz_hip_render(&sd, &cd, &p, rgb.data(), &stats);
             if (rc == RAYZ_OK)
                 for (size_t i = 0; i < n; ++i) img.pixels[i] = V3{rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]};
         } else {
             std::vector<double> rgb(n * 3);
-            rc = multi ? rayz_hip_render_multi_f64(gpu.devices.data(), (int)gpu.devices.size(), &sd, &cd, &p, rgb.data(), &stats)
-                       : rayz_hip_render_f64(&sd, &cd, &p, rgb.data(), &stats);
+            rc = multi ? rayz_hip_multi_render_f64(mh, &cd, &p, rgb.data(), &stats) : rayz_hip_render_f64(&sd, &cd, &p, rgb.data(), &stats);
             if (rc == RAYZ_OK)
                 for (size_t i = 0; i < n; ++i) img.pixels[i] = V3{rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]};
         }

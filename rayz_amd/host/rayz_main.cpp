@@ -36,13 +36,17 @@ int main(int argc, char** argv) {
     if ((e = std::getenv("RAYZ_TRAVERSAL")))
         tracer.gpu.traversal = std::string(e) == "bvh" ? RAYZ_TRAVERSAL_BVH : std::string(e) == "linear" ? RAYZ_TRAVERSAL_LINEAR : RAYZ_TRAVERSAL_AUTO;
 
-    if ((e = std::getenv("RAYZ_DEVICES"))) {
-        for (const char* q = e; *q;) {
+    if ((e = std::getenv("RAYZ_DEVICES"))) { // "0,1,2": anything else is an error, not a silent fall-back to device 0
+        for (const char* q = e;;) {
             char* next = nullptr;
             const long d = std::strtol(q, &next, 10);
-            if (next == q) break;
+            if (next == q || d < 0 || d >= RAYZ_MAX_DEVICES || (*next != ',' && *next != '\0')) {
+                std::fprintf(stderr, "error: RAYZ_DEVICES=\"%s\" is not a comma-separated list of device ordinals\n", e);
+                return 2;
+            }
             tracer.gpu.devices.push_back((int)d);
-            q = *next == ',' ? next + 1 : next;
+            if (*next == '\0') break;
+            q = next + 1;
         }
     }
 

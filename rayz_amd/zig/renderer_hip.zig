@@ -107,6 +107,27 @@ extern "c" fn rayz_hip_render_multi(
     stats: ?*RayzRenderStats,
 ) c_int;
 
+// A caller that renders more than one frame on several GPUs keeps ONE handle (per-device scenes + the RCCL
+// communicators, `ncclCommInitAll`: tens of milliseconds per device) instead of paying the one-shot form's
+// create + destroy per frame: rayz_hip_multi_create once, rayz_hip_multi_render per frame, rayz_hip_multi_destroy at
+// the end (HipOptions.multi).  NOTE: with more than one DISTINCT device this path has not yet run on hardware.
+pub const RayzMulti = opaque {};
+extern "c" fn rayz_hip_multi_create(
+    devices: [*]const c_int,
+    n_devices: c_int,
+    scene: *const RayzSceneDesc,
+    transport: u32, // 0 = RCCL gather, 1 = peer copies
+    out: *?*RayzMulti,
+) c_int;
+extern "c" fn rayz_hip_multi_render(
+    multi: *RayzMulti,
+    camera: *const RayzCameraDesc,
+    params: *const RayzRenderParams,
+    rgb_out: [*]f32,
+    stats: ?*RayzRenderStats,
+) c_int;
+extern "c" fn rayz_hip_multi_destroy(multi: ?*RayzMulti) c_int;
+
 fn v3(v: vec.V3) [3]f64 {
     return .{ v.x, v.y, v.z };
 }
@@ -115,6 +136,9 @@ pub const HipOptions = struct {
     seed: ?u64 = null, // null: next u64 of the Tracer's own DefaultPrng
     tmin: f64 = 1e-3,
     devices: []const c_int = &.{}, // empty: device 0; e.g. &.{ 0, 1, 2, 3, 4, 5, 6, 7 } for a whole MI355X node
+    // in/out: a handle kept across frames for `devices` (null: created by the first renderHip call that has devices;
+    // the caller releases it with rayz_hip_multi_destroy).  The pool must not change while it is kept.
+    multi: ?*?*RayzMulti = null,
 };
 
 /// The body of `Tracer.render()`: flatten → one extern call → widen f32 → f64 into img.pixels.
@@ -172,8 +196,13 @@ pub fn renderHip(self: *renderer.Tracer, opt: HipOptions) !usize {
     var stats: RayzRenderStats = undefined;
     const rc = if (opt.devices.len == 0)
         (if (rayz_hip_init(0) != 0) @as(c_int, -4) else rayz_hip_render(&scene, &cam, &params, rgb.ptr, &stats))
-    else
-        rayz_hip_render_multi(opt.devices.ptr, @intCast(opt.devices.len), &scene, &cam, &params, rgb.ptr, &stats);
+    else if (opt.multi) |slot| blk: {
+        if (slot.* == null) {
+            const crc = rayz_hip_multi_create(opt.devices.ptr, @intCast(opt.devices.len), &scene, 0, slot);
+            if (crc != 0) break :blk crc;
+        }
+        break :blk rayz_hip_multi_render(slot.*.?, &cam, &params, rgb.ptr, &stats);
+    } else rayz_hip_render_multi(opt.devices.ptr, @intCast(opt.devices.len), &scene, &cam, &params, rgb.ptr, &stats);
     if (rc != 0) {
         std.debug.print("rayz_hip: {s}\n", .{rayz_hip_last_error()});
         return error.GpuRenderFailed;

@@ -39,6 +39,19 @@ def test_bench_json_contract(gpu):
     assert d["also"]["f64_flat_list"]["value"] > 0 and d["also"]["f64_bvh_traversal"]["roofline"]["bound"] == "valu_fp32"
     m = d["also"]["c_abi_multi_device_entry"]  # rayz_hip_multi_render on one device: RCCL really ran
     assert m["value"] > 0 and m["n_devices"] == 1 and m["rccl_version"] > 0 and m["identical_to_device_path"] is True
+    assert m["gather_ms"] > 0 and len(m["per_device_kernel_ms"]) == 1
+    # the f64 fidelity mode's entries claim no utilisation fraction (its f64 work is not counted), only the filter's share
+    assert d["also"]["f64_bvh_traversal"]["roofline"]["frac"] is None and d["also"]["f64_bvh_traversal"]["roofline"]["filter_frac"] > 0
+    # every BASELINE config rides along: 2 (flat + BVH), 4 (one GPU's 1/8 share, BVH + flat at reduced spp), 5 (mesh, BVH)
+    for k in ("config2_flat_list", "config2_bvh", "config4_one_gpu_share_bvh", "config4_one_gpu_share_flat_list", "config5_triangle_mesh_bvh"):
+        e = d["also"][k]
+        assert e["value"] > 0 and e["kernel_ms"] > 0 and e["segments_per_sample"] >= 1 and e["roofline"]["frac"] > 0 and e["workload"], k
+    assert d["also"]["config4_one_gpu_share_bvh"]["spp"] == 16 and "rows r % 8 == 0" in d["also"]["config4_one_gpu_share_bvh"]["workload"]
+    pr = d["per_rank"]
+    assert pr["kernel_ms"]["min"] <= pr["kernel_ms"]["mean"] <= pr["kernel_ms"]["max"] and len(pr["kernel_ms"]["all"]) == 1
+    assert pr["gather_ms"]["max"] > 0 and d["roofline"]["kernel_ms"] == pr["kernel_ms"]["max"]
+    rfm = d["roofline"]["reference_formulation"]
+    assert rfm["frac"] is None or rfm["frac"] <= 1
     hb = d["roofline"]["hbm"]
     assert hb["algorithmic_bytes"] < hb["workspace_bytes"] * 10 and hb["chunk_sums_per_pixel"] >= 1
 

@@ -1,6 +1,6 @@
 """`bench.py --gpus N` must never print a line for fewer GPUs than it was asked for: without a launcher it starts
 N ranks itself (torch.distributed.run) or fails; with a WORLD_SIZE that disagrees it fails.  In this container there
-is no GPU, so both cases must exit non-zero without a JSON line."""
+is no GPU, so both cases must exit non-zero without a JSON line.  The launching parent stays GPU-free."""
 import os
 import subprocess
 import sys
@@ -29,6 +29,23 @@ def test_gpus_2_without_launcher_spawns_or_fails():
     else:
         assert r.returncode != 0 and not lines
         assert "visible" in r.stderr
+
+
+def test_launcher_parent_stays_gpu_free():
+    """The parent that starts the ranks must not touch a GPU runtime (a process that has may not start other GPU programs
+    on the pool's boxes): it counts devices from sysfs and imports neither torch nor the library."""
+    code = ("import sys, bench; n = bench.visible_gpu_count(); "
+            "assert 'torch' not in sys.modules and 'rayz_amd' not in sys.modules, sorted(sys.modules); "
+            "print('count', n)")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=120)
+    assert r.returncode == 0 and r.stdout.startswith("count"), r.stderr[-1000:]
+    src = open(BENCH).read()
+    body = src[src.index("def launch_ranks"):src.index("def main()")]
+    assert "import torch" not in body and "device_count" not in body
+    # HIP_VISIBLE_DEVICES narrows the count without any runtime call
+    r = subprocess.run([sys.executable, "-c", "import bench; print(bench.visible_gpu_count())"], capture_output=True, text=True,
+                       cwd=ROOT, env=dict(os.environ, HIP_VISIBLE_DEVICES=""), timeout=120)
+    assert r.stdout.strip() in ("0", "None")
 
 
 def test_world_size_mismatch_fails():

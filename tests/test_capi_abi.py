@@ -263,3 +263,10 @@ def test_chunk_schedule_properties_and_oracle_agreement(built, oracle):
     out = np.zeros((4, 4, 3), dtype=np.float32)
     rc = lib.rayz_hip_render(C.byref(t.scene_desc()), C.byref(t.camera_desc()), C.byref(p), out.ctypes.data_as(C.c_void_p), None)
     assert rc == capi.ERR_BAD_ARG and b"chunks per pixel" in lib.rayz_hip_last_error()
+    # the automatic schedule (chunk_spp = 0) is bounded the same way: a small frame uses uniform chunks of 16
+    p = capi.RenderParams(width=4, height=4, samples_per_px=1 << 25, chunk_spp=0)
+    rc = lib.rayz_hip_render(C.byref(t.scene_desc()), C.byref(t.camera_desc()), C.byref(p), out.ctypes.data_as(C.c_void_p), None)
+    assert rc == capi.ERR_BAD_ARG and b"chunks per pixel" in lib.rayz_hip_last_error()
+    assert lib.rayz_hip_chunk_schedule(C.byref(p), None, 0) == 0  # .. and the schedule query says "none" instead of building 2^21 entries
+    p = capi.RenderParams(width=1920, height=1080, samples_per_px=1 << 25, chunk_spp=0)  # 256-sample chunks: 2^17 of them, fine
+    assert lib.rayz_hip_chunk_schedule(C.byref(p), None, 0) == (1 << 17) + 4  # 2^17 - 1 chunks of 256, then 128, 64, 32, 16, 16

@@ -91,3 +91,17 @@ def test_conservative_filter_on_the_device(gpu, oracle):
     q, dd = c - rec[:, 7:10], K.unit(rec[:, 10:13])
     miss = np.linalg.norm(q - (q * dd).sum(1, keepdims=True) * dd, axis=1) - r
     assert (miss > 0.016).sum() > 1000 and (g[miss > 0.016, 9] == 0).all()
+
+
+def test_kat_refuses_a_uniform_list_that_leaves_the_record(gpu):
+    """n_u is the caller's: a list that would run past the record's 48 doubles (the device reads u[0 .. n_u)) is refused on
+    the host with RAYZ_ERR_BAD_ARG, as is a negative, fractional or NaN count."""
+    for op, at, cap in ((capi.KAT_GET_RAY, 21, 26), (capi.KAT_SCATTER, 16, 31)):
+        rec = K.blank(3)
+        rec[:, at] = cap
+        gpu.kat(op, rec)  # the largest list that fits
+        for bad in (cap + 1, -1, 2.5, float("nan"), 1e30):
+            rec = K.blank(3)
+            rec[2, at] = bad
+            with pytest.raises(capi.RayzHipError, match="n_u"):
+                gpu.kat(op, rec)
