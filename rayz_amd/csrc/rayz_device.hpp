@@ -1043,6 +1043,10 @@ template <class R> struct BvhQuery {
     uint32_t cur;   // what the lane holds: an inner node to visit (< kBvhDone), a parked leaf (kBvhLeafFlag | descriptor),
                     // or kBvhDone — then the stack is empty as well and the walk is complete
     uint32_t sp;    // index of the stack's top entry; entry 0 is a kBvhDone sentinel, so popping an empty stack ends the walk
+    uint32_t top;   // the stack's top entry, stack[sp], read AHEAD: every step (and bvh_pop) ends by loading the entry that
+                    // will be the top at the next pop, so that a pop takes a register instead of waiting for an LDS round
+                    // trip between the box tests and the next node fetch (the walk is latency-bound per wave: 49 % of a
+                    // wave's cycles are waits, profiles/r02)
     // the reject test's orthonormal pair, made once per segment by the set-up instead of once per leaf
     // phase (a square root and a division, ≈35 vector instructions, ≈3 times per segment at ≈26 lanes).  R = float only: the
     // f64 kernel sits at 128 VGPRs and keeps making it at the leaves (LeafBasis<double> is empty).
@@ -1090,6 +1094,7 @@ template <class R> __device__ __forceinline__ void bvh_begin(BvhQuery<R>& q, V<R
     q.ibest = -1;
     q.cur = n_inner ? 0u : kBvhDone;
     q.sp = 0;
+    q.top = kBvhDone; // = stack[0], the sentinel
 }
 
 // Slab test (AABB.hit, src/hit.zig:70-98) with 1/d and −o/d hoisted: each plane distance is one fma.  It is
@@ -1172,16 +1177,18 @@ __device__ __forceinline__ void bvh_node_step(const DevScene<R>& sc, const f4* n
     const uint32_t near = mask_select(swap, r, l), far = mask_select(swap, l, r);
     stack[256 * (q.sp + 1u)] = far; // lands above the top unless both were hit
     const uint32_t sp = mask_add(q.sp, both);
-    const uint32_t e = stack[256 * sp]; // read by every stepping lane, used when nothing was hit (never the word just written)
-    q.cur = mask_select(none, e, near);
-    q.sp = mask_sub(sp, none); // popping the sentinel leaves sp at −1: the lane holds kBvhDone and touches the stack no
-                               // more until bvh_begin
+    q.cur = mask_select(none, q.top, near); // nothing hit => nothing pushed: the entry read ahead IS the top
+    q.sp = mask_sub(sp, none); // popping the sentinel leaves sp at −1: the lane holds kBvhDone and steps no more until
+                               // bvh_begin (its read-ahead below lands in the guard row under the stack)
+    q.top = stack[256 * q.sp]; // read ahead for the NEXT pop — after the store above (LDS keeps a wave's order), consumed
+                               // one step later, behind that step's node fetch: its latency is off the critical path
 }
 
 // The next entry of a lane that is done with its parked leaf.
 template <class R> __device__ __forceinline__ void bvh_pop(BvhQuery<R>& q, const uint32_t* stack) {
-    q.cur = stack[256 * q.sp];
+    q.cur = q.top;
     q.sp -= 1u;
+    q.top = stack[256 * q.sp];
 }
 
 // The reject test of a leaf entry (general velocity form of DESIGN.md §4.3, f32 for both precisions): the ONE place it is
@@ -1281,6 +1288,7 @@ template <class R> __global__ __launch_bounds__(256, bvh_waves<R>()) void trace_
     q.ibest = -1;
     q.cur = kBvhDone;
     q.sp = 0;
+    q.top = kBvhDone;
     q.lb.make(ud, o);
     // dynamic shared memory, from LDS address 0 (the kernel has no static LDS): the top of the tree, copied once per
     // workgroup (A.bvh_top_words u32s; a node's LDS address is its index << 6 for f32), then the per-lane traversal stacks,
@@ -1293,7 +1301,7 @@ template <class R> __global__ __launch_bounds__(256, bvh_waves<R>()) void trace_
         return;
     }
     f4* top = (f4*)lds_words;
-    uint32_t* stack = lds_words + A.bvh_top_words + threadIdx.x;
+    uint32_t* stack = lds_words + A.bvh_top_words + 256u + threadIdx.x; // (one guard row under entry 0: BvhQuery::top)
     for (uint32_t k = threadIdx.x; k < 4u * A.sc.bvh_top; k += 256u) top[k] = A.sc.bvh_nodes[k];
     stack[0] = kBvhDone; // the sentinel under every lane's stack
     __syncthreads();
@@ -1527,7 +1535,7 @@ template <class R> __global__ __launch_bounds__(256, RAYZ_BVH2_WAVES) void trace
         return;
     }
     f4* top = (f4*)lds_words;
-    uint32_t* stack = lds_words + A.bvh_top_words + threadIdx.x;
+    uint32_t* stack = lds_words + A.bvh_top_words + 256u + threadIdx.x; // (one guard row under entry 0: BvhQuery::top)
     for (uint32_t k = threadIdx.x; k < 4u * A.sc.bvh_top; k += 256u) top[k] = A.sc.bvh_nodes[k];
     stack[0] = kBvhDone;
     __syncthreads();
@@ -1556,6 +1564,7 @@ template <class R> __global__ __launch_bounds__(256, RAYZ_BVH2_WAVES) void trace
     q.ibest = -1;
     q.cur = kBvhDone;
     q.sp = 0;
+    q.top = kBvhDone;
     q.lb.make(ud, o);
     bool w_has = false; // the walker holds a context (walking while q.cur != kBvhDone, complete after)
     bool wsel = false;

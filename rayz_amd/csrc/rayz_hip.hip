@@ -802,7 +802,8 @@ int render_impl(RayzScene* s, const DeviceCtx& ctx, SceneBuffers<R>& b, const Ra
     int blocks_per_cu = 0;
     // the BVH kernel's LDS stack holds one entry per tree level below the root (nearer child first: the stack never
     // holds more than one entry per level); sized from THIS tree, so a shallow tree does not cap the occupancy
-    const size_t bvh_stack_bytes = use_bvh ? ((size_t)s->bvh_dev.depth + 2) * block * sizeof(uint32_t) : 0;
+    // (+ one guard row under entry 0: a lane that has popped its sentinel reads ahead at index −1)
+    const size_t bvh_stack_bytes = use_bvh ? ((size_t)s->bvh_dev.depth + 3) * block * sizeof(uint32_t) : 0;
     const size_t bvh_top_bytes = use_bvh ? (size_t)b.bvh_top * 4 * sizeof(f4) : 0; // the tree's top: first in LDS
     // (+ RAYZ_DEBUG_LDS_PAD unused bytes: an occupancy experiment — fewer workgroups per CU, the same code)
     const size_t bvh_lds = bvh_top_bytes + bvh_stack_bytes + (use_bvh ? (size_t)tuning(RAYZ_DEBUG_LDS_PAD, 0) : 0);
