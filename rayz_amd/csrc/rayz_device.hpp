@@ -1399,6 +1399,14 @@ template <class R> __global__ __launch_bounds__(256, bvh_waves<R>()) void trace_
                 if (can_step) bvh_node_step<R>(A.sc, A.sc.bvh_nodes, q, tmin32, stack, fetch_ticks);
 #else
                 if (can_step) bvh_node_step<R>(A.sc, A.sc.bvh_nodes, q, tmin32, stack);
+                // .. and a second step for the lanes that still hold an inner node, without a new wave-level decision (lane
+                // counts against thresholds are scalar work with a taken branch at its end: every other step is enough —
+                // +1 % on configs 3 / 5, +2.6 % on config 2, profiles/r03/bvh_step/unroll.log; three or four lose it again)
+                {
+                    const bool again = q.cur < kBvhDone;
+                    node_tests += 2u * (uint32_t)__popcll(__ballot(again));
+                    if (again) bvh_node_step<R>(A.sc, A.sc.bvh_nodes, q, tmin32, stack);
+                }
 #endif
                 node_tests += 2u * (uint32_t)n_can;
             }
