@@ -302,9 +302,9 @@ int rayz_hip_tonemap_u8(const float* d_rgb, uint8_t* d_rgb8, size_t n_pixels, vo
  * Evaluates the trace kernels' OWN device functions (the same inlined code the kernels run) on caller inputs, one
  * GPU thread per record, so that the reference's test vectors and a CPU restatement can be held against the
  * device code directly.  Covered: everything a path is assembled from, the BVH kernels' leaf reject test
- * (leaf_reject_test, shared with the walk) included.  NOT covered: the flat list's packed-FMA form of that test
- * (ScanGroup::discs, two spheres per v_pk_fma_f32 off scalar registers) — it has no per-record form; whole-frame
- * renders hold it to the oracle bit for bit instead (tests/test_gpu_parity.py).  Vectors: src/material.zig:213-223 (refract), src/renderer.zig:129-149 (get ray),
+ * (leaf_reject_test, shared with the walk) and the flat list's packed-FMA form of it (ScanGroup::discs, two spheres
+ * per v_pk_fma_f32: RAYZ_KAT_SCAN_DISCS; in the scan loop its sphere operands come from scalar registers, here from
+ * vector ones — the same arithmetic) included.  Vectors: src/material.zig:213-223 (refract), src/renderer.zig:129-149 (get ray),
  * src/hit.zig:247-279 (bbox hit); tests/test_kat_gpu.py.  Host buffers: `in` = n records of RAYZ_KAT_IN_STRIDE
  * doubles, `out` = n records of RAYZ_KAT_OUT_STRIDE doubles (unused slots 0).  Values are narrowed to `precision`
  * as a scene is when it crosses the ABI.  Random draws, where an op makes any, come from the record's list u[]
@@ -326,8 +326,14 @@ typedef enum RayzKatOp {
                                  out: scattered[0] dir[1..3] draws[4]                                   src/material.zig:73-160 */
     RAYZ_KAT_CHECKER = 6,     /* in: point[0..2] scale[3]                          out: parity[0]       src/material.zig:32-36 */
     RAYZ_KAT_BACKGROUND = 7,  /* in: dir[0..2]                                     out: colour[0..2]    src/renderer.zig:124-125 */
-    RAYZ_KAT_TRIANGLE_HIT = 8 /* in: v0[0..2] v1[3..5] v2[6..8] origin[9..11] dir[12..14] tmin[15] tmax[16]
+    RAYZ_KAT_TRIANGLE_HIT = 8,/* in: v0[0..2] v1[3..5] v2[6..8] origin[9..11] dir[12..14] tmin[15] tmax[16]
                                  out: hit[0] t[1] passed_filter[2]                 build-defined */
+    RAYZ_KAT_SCAN_DISCS = 9   /* one 4-sphere block of the flat list's scan streams, as the SCAN LOOP evaluates it (packed FMAs,
+                                 two spheres per instruction; the values are f32 for both precisions):
+                                 in: cx[0..3] cy[4..7] cz[8..11] radius[12..15] (padded and squared by the library as the scene
+                                     upload does) vy[16..19] origin[20..22] dir[23..25] time[26] class[27] (0 static, 1 y-moving)
+                                 out: r2 - p1^2 - p2^2 per sphere [0..3] (>= 0: candidate), the same value from the
+                                      general-velocity form the BVH leaves use [4..7]     src/geom.zig:40-50, DESIGN.md 4.3 */
 } RayzKatOp;
 #define RAYZ_KAT_IN_STRIDE 48
 #define RAYZ_KAT_OUT_STRIDE 12

@@ -1418,6 +1418,25 @@ template <class R> static void katB(uint32_t op, const double* a, double* r) {
         break;
     }
     case RAYZ_KAT_CHECKER: r[0] = (double)checkerParity<R>(v3(0), (R)a[3]); break;
+    case RAYZ_KAT_SCAN_DISCS: { // the flat list's reject test on a block of 4 spheres: sphereFilter, the ONE form mode B has
+        const V<R> o = v3(20), d = v3(23);
+        const V<R> udk = unit(d);
+        const Basis<float> b = makeBasis<float>(V<float>{(float)udk.x, (float)udk.y, (float)udk.z}, V<float>{(float)o.x, (float)o.y, (float)o.z});
+        const float ft = (float)(R)a[26];
+        double S = norm3(a + 20);
+        RayzSphere q[4] = {};
+        for (int k = 0; k < 4; ++k) {
+            q[k].center[0] = a[k], q[k].center[1] = a[4 + k], q[k].center[2] = a[8 + k];
+            q[k].radius = a[12 + k];
+            q[k].velocity[1] = a[27] != 0.0 ? a[16 + k] : 0.0;
+            S = std::max(S, norm3(q[k].center) + norm3(q[k].velocity) + std::fabs(q[k].radius));
+        }
+        for (int k = 0; k < 4; ++k) {
+            const V<float> c{(float)a[k], (float)a[4 + k], (float)a[8 + k]}, v{0.0f, (float)q[k].velocity[1], 0.0f};
+            r[k] = r[4 + k] = (double)sphereFilter<float>(b, ft, c, v, padRadius2Scan<R>(q[k], S));
+        }
+        break;
+    }
     case RAYZ_KAT_BACKGROUND: put3(0, background<R>(unit(v3(0)))); break;
     case RAYZ_KAT_TRIANGLE_HIT: {
         const V<R> v0 = v3(0), o = v3(9), d = v3(12);
@@ -1498,6 +1517,16 @@ static void katA(uint32_t op, const double* a, double* r) {
         break;
     }
     case RAYZ_KAT_CHECKER: r[0] = (double)checkerParity(v3(a), a[3]); break;
+    case RAYZ_KAT_SCAN_DISCS: { // the reference's own discriminant (src/geom.zig:40-50) for the four spheres: sign only
+        const V3 o = v3(a + 20), d = v3(a + 23);
+        for (int k = 0; k < 4; ++k) {
+            const V3 c{a[k], a[4 + k] + (a[27] != 0.0 ? a[16 + k] * a[26] : 0.0), a[8 + k]};
+            const V3 oc = c.sub(o);
+            const double aa = d.dot(d), hb = d.dot(oc), cc = oc.dot(oc) - a[12 + k] * a[12 + k];
+            r[k] = r[4 + k] = hb * hb - aa * cc;
+        }
+        break;
+    }
     case RAYZ_KAT_BACKGROUND: put3(0, background(v3(a))); break;
     case RAYZ_KAT_TRIANGLE_HIT: {
         Triangle t{v3(a), v3(a + 3), v3(a + 6), 0};
@@ -1516,7 +1545,7 @@ static void katA(uint32_t op, const double* a, double* r) {
 extern "C" {
 
 int rayz_oracle_kat_b(uint32_t op, uint32_t precision, const double* in, uint32_t n, double* out) {
-    if (op > RAYZ_KAT_TRIANGLE_HIT || precision > RAYZ_PRECISION_F64 || (n && (!in || !out))) return RAYZ_ERR_BAD_ARG;
+    if (op > RAYZ_KAT_SCAN_DISCS || precision > RAYZ_PRECISION_F64 || (n && (!in || !out))) return RAYZ_ERR_BAD_ARG;
     for (uint32_t i = 0; i < n; ++i) {
         double* r = out + (size_t)i * RAYZ_KAT_OUT_STRIDE;
         std::fill(r, r + RAYZ_KAT_OUT_STRIDE, 0.0);
@@ -1526,7 +1555,7 @@ int rayz_oracle_kat_b(uint32_t op, uint32_t precision, const double* in, uint32_
     return RAYZ_OK;
 }
 int rayz_oracle_kat_a(uint32_t op, const double* in, uint32_t n, double* out) {
-    if (op > RAYZ_KAT_TRIANGLE_HIT || (n && (!in || !out))) return RAYZ_ERR_BAD_ARG;
+    if (op > RAYZ_KAT_SCAN_DISCS || (n && (!in || !out))) return RAYZ_ERR_BAD_ARG;
     for (uint32_t i = 0; i < n; ++i) {
         double* r = out + (size_t)i * RAYZ_KAT_OUT_STRIDE;
         std::fill(r, r + RAYZ_KAT_OUT_STRIDE, 0.0);

@@ -1926,6 +1926,40 @@ template <class R> __global__ __launch_bounds__(64) void kat_kernel(uint32_t op,
         r[2] = f >= R(0) ? 1.0 : 0.0;
         break;
     }
+    case 9: { // SCAN_DISCS: one block of the flat list's scan, THROUGH the packed-FMA form the scan loop runs
+              // (ScanGroup<float, cls>::discs: two spheres per v_pk_fma_f32), plus the general-velocity form of the BVH
+              // leaves on the same spheres: cx[4] cy[4] cz[4] radius[4] vy[4] o(3) d(3) time cls (+ padded r²[4] at 28, from the
+              // host) -> disc[4] leaf_disc[4]
+        const V<R> o = v3(20), d = v3(23);
+        const V<R> ud = unit(d);
+        const RayBasis<float> b = make_basis<float>(V<float>{(float)ud.x, (float)ud.y, (float)ud.z}, V<float>{(float)o.x, (float)o.y, (float)o.z});
+        const float ft = (float)(R)a[26];
+        float out4[4];
+        if (a[27] == 0.0) {
+            ScanGroup<float, 0> g;
+            for (int q = 0; q < 2; ++q) {
+                g.cx[q] = f2{(float)a[2 * q], (float)a[2 * q + 1]}, g.cy[q] = f2{(float)a[4 + 2 * q], (float)a[5 + 2 * q]};
+                g.cz[q] = f2{(float)a[8 + 2 * q], (float)a[9 + 2 * q]}, g.r2[q] = f2{(float)a[28 + 2 * q], (float)a[29 + 2 * q]};
+            }
+            g.discs(out4, b, ft);
+        } else {
+            ScanGroup<float, 1> g;
+            for (int q = 0; q < 2; ++q) {
+                g.cx[q] = f2{(float)a[2 * q], (float)a[2 * q + 1]}, g.cy[q] = f2{(float)a[4 + 2 * q], (float)a[5 + 2 * q]};
+                g.cz[q] = f2{(float)a[8 + 2 * q], (float)a[9 + 2 * q]}, g.r2[q] = f2{(float)a[28 + 2 * q], (float)a[29 + 2 * q]};
+                g.vy[q] = f2{(float)a[16 + 2 * q], (float)a[17 + 2 * q]};
+            }
+            g.discs(out4, b, ft);
+        }
+        for (int k = 0; k < 4; ++k) {
+            r[k] = (double)out4[k];
+            const float vy = a[27] == 0.0 ? 0.0f : (float)a[16 + k];
+            const float p1 = fm(0.0f, ft * b.e1z, fm(0.0f, ft * b.e1x, basis_p1<float>(b, (float)a[k], (float)a[8 + k])));
+            const float p2 = fm(0.0f, ft * b.e2z, fm(vy, ft * b.e2y, fm(0.0f, ft * b.e2x, basis_p2<float>(b, (float)a[k], (float)a[4 + k], (float)a[8 + k]))));
+            r[4 + k] = (double)basis_disc<float>(p1, p2, (float)a[28 + k]);
+        }
+        break;
+    }
     default: break;
     }
 }

@@ -23,6 +23,7 @@
 #include <limits>
 #include <mutex>
 #include <algorithm>
+#include <atomic>
 #include <new>
 #include <type_traits>
 #include <vector>
@@ -65,12 +66,12 @@ DeviceCtx g_ctx[RAYZ_MAX_DEVICES];
 // Measurement knobs (rayz_hip_debug_set; they change scheduling or the walked tree, never an image).  The library reads
 // no environment variable: a stray one cannot change a production render.  -1 = the built-in default.
 struct Tuning {
-    long long v[RAYZ_DEBUG_KNOBS];
-    Tuning() { for (auto& x : v) x = -1; }
+    std::atomic<long long> v[RAYZ_DEBUG_KNOBS];
+    Tuning() { for (auto& x : v) x.store(-1, std::memory_order_relaxed); }
 };
-Tuning g_tune; // guarded by g_mu when written; renders read a snapshot
+Tuning g_tune; // written by rayz_hip_debug_set, read (once per knob) by the render / scene build that starts next
 long long tuning(int knob, long long dflt) {
-    const long long x = g_tune.v[knob];
+    const long long x = g_tune.v[knob].load(std::memory_order_relaxed);
     return x < 0 ? dflt : x;
 }
 int g_default = -1; // device of the last successful rayz_hip_init: what entry points without a device argument use
@@ -1281,8 +1282,7 @@ uint32_t rayz_hip_abi_version(void) { return RAYZ_HIP_ABI_VERSION; }
 
 int rayz_hip_debug_set(uint32_t knob, long long value) {
     if (knob >= RAYZ_DEBUG_KNOBS) return fail(RAYZ_ERR_BAD_ARG, "bad debug knob %u", knob);
-    std::lock_guard<std::mutex> lock(g_mu);
-    g_tune.v[knob] = value;
+    g_tune.v[knob].store(value, std::memory_order_relaxed);
     return RAYZ_OK;
 }
 const char* rayz_hip_last_error(void) { return g_err; }
@@ -1423,7 +1423,7 @@ int rayz_hip_tonemap_u8(const float* d_rgb, uint8_t* d_rgb8, size_t n_pixels, vo
 // ---- known answers: the kernel's device functions on caller inputs ---------------------------------------------
 int rayz_hip_kat(uint32_t op, uint32_t precision, const double* in, uint32_t n, double* out) {
     return guarded([&] {
-        if (op > RAYZ_KAT_TRIANGLE_HIT) return fail(RAYZ_ERR_BAD_ARG, "bad known-answer op %u", op);
+        if (op > RAYZ_KAT_SCAN_DISCS) return fail(RAYZ_ERR_BAD_ARG, "bad known-answer op %u", op);
         if (precision > RAYZ_PRECISION_F64) return fail(RAYZ_ERR_BAD_ARG, "bad precision %u", precision);
         if (!n) return (int)RAYZ_OK;
         if (!in || !out) return fail(RAYZ_ERR_BAD_ARG, "null buffer");
@@ -1444,6 +1444,18 @@ int rayz_hip_kat(uint32_t op, uint32_t precision, const double* in, uint32_t n, 
                 const double nu = a[at];
                 if (!(nu >= 0 && nu <= RAYZ_KAT_IN_STRIDE - (at + 1) && nu == std::floor(nu)))
                     return fail(RAYZ_ERR_BAD_ARG, "record %u: n_u = %g is not an integer in [0, %d]", i, nu, RAYZ_KAT_IN_STRIDE - (at + 1));
+            }
+            if (op == RAYZ_KAT_SCAN_DISCS) { // the padded squares the scan streams would hold for these four spheres
+                double S = norm3(a + 20);
+                RayzSphere q[4] = {};
+                for (int k = 0; k < 4; ++k) {
+                    q[k].center[0] = a[k], q[k].center[1] = a[4 + k], q[k].center[2] = a[8 + k];
+                    q[k].radius = a[12 + k];
+                    q[k].velocity[1] = a[27] != 0.0 ? a[16 + k] : 0.0;
+                    S = std::max(S, norm3(q[k].center) + norm3(q[k].velocity) + std::fabs(q[k].radius));
+                }
+                for (int k = 0; k < 4; ++k)
+                    a[28 + k] = precision == RAYZ_PRECISION_F32 ? (double)pad_radius2_scan<float>(q[k], S) : (double)pad_radius2_scan<double>(q[k], S);
             }
             if (op == RAYZ_KAT_SPHERE_HIT) {
                 RayzSphere q{};

@@ -31,7 +31,7 @@ from rayz_amd import capi  # noqa: E402
 
 OPS = {"refract": capi.KAT_REFRACT, "reflectance": capi.KAT_REFLECTANCE, "get_ray": capi.KAT_GET_RAY, "box_hit": capi.KAT_BOX_HIT,
        "sphere_hit": capi.KAT_SPHERE_HIT, "scatter": capi.KAT_SCATTER, "checker": capi.KAT_CHECKER, "background": capi.KAT_BACKGROUND,
-       "triangle_hit": capi.KAT_TRIANGLE_HIT}
+       "triangle_hit": capi.KAT_TRIANGLE_HIT, "scan_discs": capi.KAT_SCAN_DISCS}
 
 
 def records():
@@ -53,6 +53,7 @@ def records():
         "checker": K.random_checkers(rng, 600),
         "background": bg,
         "triangle_hit": K.random_triangles(rng, 1200),
+        "scan_discs": K.random_scan_blocks(rng, 1500),  # LAST: the draws of the sets above stay what they were
     }
 
 

@@ -191,3 +191,26 @@ def random_triangles(rng, n):
     rec[:, 0:3], rec[:, 3:6], rec[:, 6:9], rec[:, 9:12], rec[:, 12:15] = f32r(v0), f32r(v1), f32r(v2), f32r(o), f32r(d)
     rec[:, 15], rec[:, 16] = 1e-3, np.inf
     return rec
+
+
+def random_scan_blocks(rng, n):
+    """Blocks of four spheres of the flat list's scan streams (RAYZ_KAT_SCAN_DISCS): small spheres on a plane as
+    randomBouncing makes them, a quarter of the blocks with the r = 1000 ground sphere in slot 0, rays aimed near one
+    sphere of the block so that about a third of the tests are candidates; half the blocks y-moving."""
+    rec = blank(n)
+    cx, cz = rng.uniform(-50, 50, (n, 4)), rng.uniform(-50, 50, (n, 4))
+    r = rng.uniform(0.15, 1.0, (n, 4))
+    cy = r.copy()
+    big = rng.random(n) < 0.25
+    cx[big, 0], cy[big, 0], cz[big, 0], r[big, 0] = 0.0, -1000.0, 0.0, 1000.0
+    cls = (rng.random(n) < 0.5).astype(np.float64)
+    cls[big] = 0.0
+    vy = rng.uniform(0, 0.5, (n, 4)) * cls[:, None]
+    o = np.stack([rng.uniform(-20, 20, n), rng.uniform(0.2, 6, n), rng.uniform(-20, 20, n)], 1)
+    k = rng.integers(0, 4, n)
+    tgt = np.stack([cx[np.arange(n), k], cy[np.arange(n), k], cz[np.arange(n), k]], 1)
+    aim = tgt + unit(rng.normal(size=(n, 3))) * (r[np.arange(n), k] * rng.uniform(0, 3.0, n))[:, None]
+    d = (aim - o) * rng.uniform(0.2, 3.0, (n, 1))
+    rec[:, 0:4], rec[:, 4:8], rec[:, 8:12], rec[:, 12:16], rec[:, 16:20] = f32r(cx), f32r(cy), f32r(cz), f32r(r), f32r(vy)
+    rec[:, 20:23], rec[:, 23:26], rec[:, 26], rec[:, 27] = f32r(o), f32r(d), uniforms(rng, n), cls
+    return rec

@@ -256,3 +256,25 @@ def test_triangle_mode_b_vs_mode_a(oracle):
     assert 0.2 < both.mean() < 0.8
     rel = np.abs(a[both, 1] - b32[both, 1]) / np.abs(a[both, 1])  # grazing rays (det -> 0) amplify without bound
     assert np.median(rel) < 2e-7 and np.quantile(rel, 0.999) < 1e-4
+
+
+def test_scan_block_filter_is_conservative_against_the_reference_discriminant(oracle):
+    """RAYZ_KAT_SCAN_DISCS on the CPU: mode B's reject test (r_pad^2 - p1^2 - p2^2, f32, the flat list's and the leaves') never
+    rejects a sphere whose line the reference's own discriminant (src/geom.zig:40-50, mode A, f64) says is met — the
+    r = 1000 ground sphere included — and it rejects the clear misses (it is a filter, not a pass-through)."""
+    rng = np.random.default_rng(31)
+    rec = K.random_scan_blocks(rng, 300_000)
+    a = oracle.kat_a(capi.KAT_SCAN_DISCS, rec)[:, :4]
+    for prec in (F32, F64):
+        b = oracle.kat_b(capi.KAT_SCAN_DISCS, rec, prec)
+        assert (b[:, :4] == b[:, 4:8]).all()  # mode B has ONE form of the test
+        hit = a >= 0
+        assert 0.1 < hit.mean() < 0.6
+        assert (b[:, :4][hit] >= 0).all(), int((b[:, :4][hit] < 0).sum())
+        # relative discriminant: a^-1 |oc|^-2-scaled; clear misses (the line passes further than 1.05 r + 1e-3 |oc| away) are filtered out
+        c = np.stack([rec[:, 0:4], rec[:, 4:8] + rec[:, 16:20] * rec[:, 26:27] * rec[:, 27:28], rec[:, 8:12]], 2)
+        oc = c - rec[:, None, 20:23]
+        dd = K.unit(rec[:, 23:26])[:, None, :]
+        dist = np.linalg.norm(oc - (oc * dd).sum(2, keepdims=True) * dd, axis=2)
+        clear = dist > 1.05 * rec[:, 12:16] + 1e-3 * np.linalg.norm(oc, axis=2)
+        assert clear.mean() > 0.3 and (b[:, :4][clear] < 0).all()

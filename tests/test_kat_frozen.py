@@ -14,7 +14,7 @@ from rayz_amd import capi
 HERE = os.path.dirname(os.path.abspath(__file__))
 OPS = {"refract": capi.KAT_REFRACT, "reflectance": capi.KAT_REFLECTANCE, "get_ray": capi.KAT_GET_RAY, "box_hit": capi.KAT_BOX_HIT,
        "sphere_hit": capi.KAT_SPHERE_HIT, "scatter": capi.KAT_SCATTER, "checker": capi.KAT_CHECKER, "background": capi.KAT_BACKGROUND,
-       "triangle_hit": capi.KAT_TRIANGLE_HIT}
+       "triangle_hit": capi.KAT_TRIANGLE_HIT, "scan_discs": capi.KAT_SCAN_DISCS}
 
 
 @pytest.fixture(scope="module")

@@ -48,6 +48,7 @@ def test_device_functions_equal_mode_b_bit_for_bit(gpu, oracle, prec):
         (capi.KAT_CHECKER, K.random_checkers(rng, 50_000)),
         (capi.KAT_BACKGROUND, bg),
         (capi.KAT_TRIANGLE_HIT, K.random_triangles(rng, 100_000)),
+        (capi.KAT_SCAN_DISCS, K.random_scan_blocks(rng, 200_000)),  # the flat list's PACKED-FMA reject test vs mode B's scalar one
     ]
     for op, rec in cases:
         got, want = gpu.kat(op, rec, prec), oracle.kat_b(op, rec, prec)
@@ -105,3 +106,13 @@ def test_kat_refuses_a_uniform_list_that_leaves_the_record(gpu):
             rec[2, at] = bad
             with pytest.raises(capi.RayzHipError, match="n_u"):
                 gpu.kat(op, rec)
+
+
+@pytest.mark.parametrize("prec", [F32, F64])
+def test_packed_scan_test_equals_the_leaf_form_on_the_device(gpu, prec):
+    """ScanGroup::discs (two spheres per v_pk_fma_f32, what the flat list's scan loop runs) and the general-velocity form
+    of the BVH leaves give the SAME value, bit for bit, for static and y-moving spheres: flat list and BVH filter alike."""
+    rec = K.random_scan_blocks(np.random.default_rng(8), 200_000)
+    got = gpu.kat(capi.KAT_SCAN_DISCS, rec, prec)
+    assert (got[:, :4] == got[:, 4:8]).all() and np.isfinite(got[:, :8]).all()
+    assert 0.1 < (got[:, :4] >= 0).mean() < 0.6
