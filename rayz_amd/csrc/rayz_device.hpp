@@ -78,7 +78,7 @@ template <class R> struct DevScene {
     const f4* bvh_nodes;     // [4 * n_inner] per INNER node, its two children's boxes IN F32 FOR BOTH PRECISIONS (the box
                              // test only culls, §4.8) — one 64-B fetch, two slab tests:
                              //   {L.lo, bits(L.id)}, {L.hi, bits(L.leaf)}, {R.lo, bits(R.id)}, {R.hi, bits(R.leaf)}
-                             //   id = the child's inner-node index; leaf = first << 4 | type1 << 3 | type0 << 2 | count
+                             //   id = the child's inner-node index << 6 (its record's byte offset); leaf = first << 4 | type1 << 3 | type0 << 2 | count
                              //   (0 for an inner child)
     const r4* bvh_leaf;      // [stride * slots] leaf order.  sphere: {c, r²}, {v, bits(hittable)};
                              //                  triangle: {v0, bits(hittable)}, {e1, 0}, {e2, 0}
@@ -87,8 +87,9 @@ template <class R> struct DevScene {
     // oversized hittables kept out of the tree (bvh_build.hpp), tested once per segment before the walk: up to 4 leaf
     // descriptors (first << 4 | type1 << 3 | type0 << 2 | count) naming slots after the tree's own in bvh_leaf / bvh_sph64
     uint32_t bvh_n_big_leaves, bvh_big[4];
-    // the first bvh_top inner-node records (the top levels of the tree, numbered breadth-first) are copied to LDS by
-    // every workgroup: a quarter of all box steps then read their node in ~100 cycles instead of a global round trip
+    // the first bvh_top / 64 inner-node records (the top levels of the tree, numbered breadth-first) are copied to LDS by
+    // every workgroup: a quarter of all box steps then read their node in ~100 cycles instead of a global round trip.
+    // In BYTES, as inner references are (index << 6).
     uint32_t bvh_top;
 };
 
@@ -1138,8 +1139,10 @@ __device__ __forceinline__ void bvh_node_step(const DevScene<R>& sc, const f4* n
         // Both homes of a node — the LDS copy of the tree's top (at LDS address 0), global memory for the rest — are read
         // from the SAME 32-bit offset (index << 6): the lanes of either kind take turns under exec, into the same
         // registers.  Two vector instructions (a compare, a shift) instead of the nine a flat-address select costs.
+        // (an inner reference IS the record's byte offset, index << 6: the host keeps the node count below 2^25; sc.bvh_top
+        //  is a byte count likewise — no shift, no second register)
         const unsigned long long in_top = __ballot(q.cur < sc.bvh_top);
-        const uint32_t off = q.cur << 6; // (the host keeps the node count below 2^25)
+        const uint32_t off = q.cur;
         unsigned long long saved;
         asm volatile("s_mov_b64 %[sv], exec\n\t"
                      "s_and_b64 exec, %[sv], %[mt]\n\t" // (SCC = some lane: an empty turn is skipped — the memory
@@ -1302,7 +1305,7 @@ template <class R> __global__ __launch_bounds__(256, bvh_waves<R>()) void trace_
     }
     f4* top = (f4*)lds_words;
     uint32_t* stack = lds_words + A.bvh_top_words + 256u + threadIdx.x; // (one guard row under entry 0: BvhQuery::top)
-    for (uint32_t k = threadIdx.x; k < 4u * A.sc.bvh_top; k += 256u) top[k] = A.sc.bvh_nodes[k];
+    for (uint32_t k = threadIdx.x; k < A.sc.bvh_top / 16u; k += 256u) top[k] = A.sc.bvh_nodes[k];
     stack[0] = kBvhDone; // the sentinel under every lane's stack
     __syncthreads();
     R time = 0;
@@ -1544,7 +1547,7 @@ template <class R> __global__ __launch_bounds__(256, RAYZ_BVH2_WAVES) void trace
     }
     f4* top = (f4*)lds_words;
     uint32_t* stack = lds_words + A.bvh_top_words + 256u + threadIdx.x; // (one guard row under entry 0: BvhQuery::top)
-    for (uint32_t k = threadIdx.x; k < 4u * A.sc.bvh_top; k += 256u) top[k] = A.sc.bvh_nodes[k];
+    for (uint32_t k = threadIdx.x; k < A.sc.bvh_top / 16u; k += 256u) top[k] = A.sc.bvh_nodes[k];
     stack[0] = kBvhDone;
     __syncthreads();
 

@@ -489,7 +489,7 @@ template <class R> int upload_bvh_body(RayzScene* s, SceneBuffers<R>& b) {
         const bool is_leaf = n.count != 0;
         nodes.push_back(f4{rayz_bvh::roundDown<float>(n.box.lo[0]), rayz_bvh::roundDown<float>(n.box.lo[1]),
                            rayz_bvh::roundDown<float>(n.box.lo[2]),
-                           Bits<float>::from(is_leaf ? (kBvhLeafFlag | leaf_info(n)) : inner_index[c])});
+                           Bits<float>::from(is_leaf ? (kBvhLeafFlag | leaf_info(n)) : (inner_index[c] << 6))}); // inner: byte offset
         nodes.push_back(f4{rayz_bvh::roundUp<float>(n.box.hi[0]), rayz_bvh::roundUp<float>(n.box.hi[1]),
                            rayz_bvh::roundUp<float>(n.box.hi[2]), 0.0f});
     };
@@ -772,7 +772,7 @@ int render_impl(RayzScene* s, const DeviceCtx& ctx, SceneBuffers<R>& b, const Ra
     A.sc.bvh_leaf_stride = b.bvh_leaf_stride;
     A.sc.bvh_n_big_leaves = use_bvh ? b.n_big_leaves : 0u;
     for (int k = 0; k < 4; ++k) A.sc.bvh_big[k] = b.big_desc[k];
-    A.sc.bvh_top = use_bvh ? b.bvh_top : 0u;
+    A.sc.bvh_top = use_bvh ? b.bvh_top * 64u : 0u; // bytes (the walk compares byte offsets)
     fill_camera<R>(cam, A.cam);
     A.partial = (r4*)s->partial;
     A.counters = s->counters;
