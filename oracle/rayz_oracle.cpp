@@ -753,13 +753,16 @@ template <class R> static R roundUp(double v) {
     return r;
 }
 
+// padding of the BVH's boxes as mode B's slab test sees them (boxHit below carries no slack of its own)
+static constexpr double kBoxPadUlps = 16.0;
+static inline double boxPad(double S, double B) { return kBoxPadUlps * (std::numeric_limits<float>::epsilon() / 2.0) * std::max(S, B); }
 // index one past the subtree of node ni (pre-order layout)
 static u32 subtreeEnd(const A::BVH& t, int ni) {
     const A::BVH::Node& n = t.nodes[ni];
     return n.left < 0 ? (u32)ni + 1 : subtreeEnd(t, n.right);
 }
 
-template <class R> static void buildBvh(const RayzSceneDesc& d, SceneB<R>& s) {
+template <class R> static void buildBvh(const RayzSceneDesc& d, SceneB<R>& s, double S) { // S: bound on every ray origin
     if (d.n_spheres + d.n_triangles == 0) return;
     std::vector<A::Hittable> hs;
     for (u32 i = 0; i < d.n_spheres; ++i) {
@@ -776,10 +779,14 @@ template <class R> static void buildBvh(const RayzSceneDesc& d, SceneB<R>& s) {
     }
     A::BVH t;
     t.build(hs, 0, hs.size());
+    double B = 0;
+    for (const A::BVH::Node& n : t.nodes)
+        for (int k = 0; k < 3; ++k) B = std::max({B, std::fabs(n.bbox.low.at(k)), std::fabs(n.bbox.high.at(k))});
+    const double pad = boxPad(S, B); // the slab test is bare: the boxes carry its slack (boxHit)
     for (size_t i = 0; i < t.nodes.size(); ++i) {
         const A::BVH::Node& n = t.nodes[i];
         typename SceneB<R>::Node o;
-        for (int k = 0; k < 3; ++k) o.lo[k] = roundDown<float>(n.bbox.low.at(k)), o.hi[k] = roundUp<float>(n.bbox.high.at(k));
+        for (int k = 0; k < 3; ++k) o.lo[k] = roundDown<float>(n.bbox.low.at(k) - pad), o.hi[k] = roundUp<float>(n.bbox.high.at(k) + pad);
         o.skip = subtreeEnd(t, (int)i);
         o.first = n.left < 0 ? (u32)n.starti : 0;
         o.count = n.left < 0 ? (u32)(n.endi - n.starti) : 0;
@@ -1027,15 +1034,14 @@ template <class R> static void triAccept(R filt, V<R> v0, V<R> e1, V<R> e2, V<R>
         ibest = prim;
     }
 }
-// slab test, src/hit.zig:70-98, with 1/d and −o/d hoisted (one fma per plane), IN F32 FOR BOTH PRECISIONS, and a relative
-// plus an absolute slack on the exit side: never culls a box the f64 narrow phase would hit.  R = float:
-// 1 + 4 ulp and 4·u·Σ|o_k / d_k|; R = double (the ray narrowed to f32: d_k rounded, −o·inv from the f64 origin rounded
-// once): 1 + 8 ulp and 8·u·Σ.  Reciprocals are held to ±2^64: a zero direction component must not reach the test as
-// ±inf — one plane of a box that straddles 0 then gives −inf, the other NaN, and max(−inf, NaN) = −inf culls a box the
-// ray lies inside.
+// slab test, src/hit.zig:70-98, with 1/d and −o/d hoisted (one fma per plane), IN F32 FOR BOTH PRECISIONS, bare (t1 ≥ t0):
+// it never culls a box the f64 narrow phase would hit because the BOXES are padded — by E = 16·u·max(S, B) per side
+// (boxPad; u = 2^-24, S ≥ |o| of every ray, B = largest box coordinate), which covers the rounding of 1/d, of −o·inv and of
+// the fma.  Reciprocals are held to ±2^64: a zero direction component must not reach the test as ±inf —
+// one plane of a box that straddles 0 then gives −inf, the other NaN, and max(−inf, NaN) = −inf culls a box the ray lies
+// inside.
 template <class R> struct SlabRay {
     V<float> inv, noi;
-    float eb;
 };
 template <class R> static SlabRay<R> slabRay(V<R> o, V<R> d) {
     SlabRay<R> s;
@@ -1047,21 +1053,17 @@ template <class R> static SlabRay<R> slabRay(V<R> o, V<R> d) {
     };
     s.inv = {inv(d.x), inv(d.y), inv(d.z)};
     s.noi = {(float)(-(o.x * (R)s.inv.x)), (float)(-(o.y * (R)s.inv.y)), (float)(-(o.z * (R)s.inv.z))};
-    auto fa = [](float v) { return std::fabs(v) <= 3.0e38f ? std::fabs(v) : 0.0f; };
-    const float u = std::numeric_limits<float>::epsilon() / 2.0f;
-    s.eb = (sizeof(R) == 8 ? 8.0f : 4.0f) * u * ((fa(s.noi.x) + fa(s.noi.y)) + fa(s.noi.z));
     return s;
 }
-// tmin rounded DOWN to f32, tbest rounded UP
+// tmin rounded DOWN to f32, tbest rounded UP; lo / hi: the PADDED box, rounded outward to f32
 template <class R> static bool boxHit(const float* lo, const float* hi, const SlabRay<R>& s, R tmin, R tbest, float& t0) {
-    const float slack = 1.0f + (sizeof(R) == 8 ? 8.0f : 4.0f) * std::numeric_limits<float>::epsilon();
     const float tmin32 = roundDown<float>((double)tmin), tb32 = roundUp<float>((double)tbest);
     const float ax = fm(lo[0], s.inv.x, s.noi.x), bx = fm(hi[0], s.inv.x, s.noi.x);
     const float ay = fm(lo[1], s.inv.y, s.noi.y), by = fm(hi[1], s.inv.y, s.noi.y);
     const float az = fm(lo[2], s.inv.z, s.noi.z), bz = fm(hi[2], s.inv.z, s.noi.z);
     t0 = std::fmax(std::fmax(std::fmin(ax, bx), std::fmin(ay, by)), std::fmax(std::fmin(az, bz), tmin32));
     const float t1 = std::fmin(std::fmin(std::fmax(ax, bx), std::fmax(ay, by)), std::fmin(std::fmax(az, bz), tb32));
-    return fm(t1, slack, s.eb) >= t0;
+    return t1 >= t0;
 }
 
 // RAYZ_TRAVERSAL_AUTO (include/rayz_hip.h): flat list up to RAYZ_AUTO_BVH_MIN hittables, BVH above
@@ -1242,7 +1244,7 @@ static int render(const RayzSceneDesc* sd, const RayzCameraDesc* cd, const RayzR
         if ((uniform ? (spp + c - 1) / c : spp / 256 + 8) >= (1ull << 20)) return RAYZ_ERR_BAD_ARG;
     }
     SceneB<R> sc = buildScene<R>(*sd, originBound(*sd, cd));
-    if (useBvh(*pp, sd->n_spheres + sd->n_triangles)) buildBvh<R>(*sd, sc);
+    if (useBvh(*pp, sd->n_spheres + sd->n_triangles)) buildBvh<R>(*sd, sc, originBound(*sd, cd));
     const CamB<R> cam = buildCamera<R>(*cd);
     const std::vector<u32> chunks = chunkSchedule(p);
     std::vector<u32> pixels; // global pixel indices, in output order
@@ -1372,8 +1374,11 @@ template <class R> static void katB(uint32_t op, const double* a, double* r) {
     }
     case RAYZ_KAT_BOX_HIT: {
         const SlabRay<R> slab = slabRay<R>(v3(6), v3(9));
-        const float lo[3] = {roundDown<float>(a[0]), roundDown<float>(a[1]), roundDown<float>(a[2])};
-        const float hi[3] = {roundUp<float>(a[3]), roundUp<float>(a[4]), roundUp<float>(a[5])};
+        double Bk = 0; // the box as the device holds it: padded for S = this ray's origin, B = this box, rounded outward
+        for (int k = 0; k < 6; ++k) Bk = std::max(Bk, std::fabs(a[k]));
+        const double pad = boxPad(norm3(a + 6), Bk);
+        const float lo[3] = {roundDown<float>(a[0] - pad), roundDown<float>(a[1] - pad), roundDown<float>(a[2] - pad)};
+        const float hi[3] = {roundUp<float>(a[3] + pad), roundUp<float>(a[4] + pad), roundUp<float>(a[5] + pad)};
         float t0;
         r[0] = boxHit<R>(lo, hi, slab, (R)a[12], (R)a[13], t0) ? 1.0 : 0.0;
         r[1] = (double)t0;

@@ -1036,7 +1036,6 @@ template <class R> struct BvhQuery {
     // the slab test runs in f32 whatever R is: it only culls, and stays conservative under the conversion (§4.8)
     V<float> inv;   // 1 / d per component (capped, bvh_begin)
     V<float> noi;   // −o · inv per component: a slab distance is ONE fma, t = fm(plane, inv, noi)
-    float eb;       // absolute slack of the slab test: Σ|noi_k| (finite components only) times BoxSlack<R>::abs
     float tb32;     // tbest as the box steps see it: rounded UP to f32 (refreshed before every run of box steps)
     double inv_a2;  // 1 / (d·d) in f64 for the narrow phase
     R tbest;
@@ -1054,14 +1053,10 @@ template <class R> struct BvhQuery {
     LeafBasis<R> lb;
 };
 
-// Slack of the f32 slab test.  R = float: relative 1 + 4 ulp (= 8u, u = 2^-24) and absolute 4u·Σ|noi|, against a need of
-// 4u and 2u (§4.8).  R = double: the ray is narrowed to f32 first (d_k rounded: one more u on inv; noi from the f64
-// origin and the f32 inv, rounded once), need 6u and 2u: 1 + 8 ulp and 8u·Σ|noi|.
-template <class R> struct BoxSlack;
-template <> struct BoxSlack<float> { static constexpr float rel = 1.0f + 4.0f * 1.1920929e-07f, abs = 4.0f * 5.9604645e-08f; };
-template <> struct BoxSlack<double> { static constexpr float rel = 1.0f + 8.0f * 1.1920929e-07f, abs = 8.0f * 5.9604645e-08f; };
-
-__device__ __forceinline__ float finite_abs(float v) { return ab(v) <= 3.0e38f ? ab(v) : 0.0f; } // 0 for ±inf / NaN
+// The f32 slab test carries NO slack of its own (round 3): the boxes the device holds are padded on the host by
+// E = kBoxPadUlps·u·max(S, B) per side (u = 2^-24; S = bound on every ray origin, B = largest box coordinate) before
+// they are rounded outward to f32 — see bvh_box_hit for why that makes the test conservative.
+constexpr double kBoxPadUlps = 16.0;
 __device__ __forceinline__ float round_up_f32(float v) { return v; }
 __device__ __forceinline__ float round_up_f32(double v) { return __double2float_ru(v); }
 __device__ __forceinline__ float round_down_f32(float v) { return v; }
@@ -1071,7 +1066,7 @@ __device__ __forceinline__ float round_down_f32(double v) { return __double2floa
 // other, and max(−inf, NaN) = −inf then culls a box the ray lies inside.  (Such directions are not exotic: a diffuse
 // scatter at |p_k| = 50 returns exactly 0 in one component about once in 10^5 bounces, when the offset is absorbed by the
 // rounding of p_k + r_k.)  With the clamp the ray is treated as one whose component is 1 / K: finite distances of the
-// right sign, and the absolute slack eb — which then carries K·|o_k| — covers their rounding.
+// right sign (the host's padding of the boxes covers their rounding: bvh_box_hit).
 constexpr float kInvCap = 0x1p64f;
 __device__ __forceinline__ float capped_inverse(float dk) { // (one v_med3_f32 behind the division)
     return __builtin_amdgcn_fmed3f(1.0f / dk, -kInvCap, kInvCap);
@@ -1087,7 +1082,6 @@ template <class R> __device__ __forceinline__ void bvh_begin(BvhQuery<R>& q, V<R
     }
     // −o·inv with the origin at full precision, rounded once
     q.noi = {(float)(-(o.x * (R)q.inv.x)), (float)(-(o.y * (R)q.inv.y)), (float)(-(o.z * (R)q.inv.z))};
-    q.eb = BoxSlack<R>::abs * ((finite_abs(q.noi.x) + finite_abs(q.noi.y)) + finite_abs(q.noi.z));
     const double ddx = d.x, ddy = d.y, ddz = d.z;
     q.inv_a2 = 1.0 / fm(ddz, ddz, fm(ddy, ddy, ddx * ddx));
     q.tbest = (R)__builtin_inff();
@@ -1098,11 +1092,18 @@ template <class R> __device__ __forceinline__ void bvh_begin(BvhQuery<R>& q, V<R
     q.top = kBvhDone; // = stack[0], the sentinel
 }
 
-// Slab test (AABB.hit, src/hit.zig:70-98) with 1/d and −o/d hoisted: each plane distance is one fma.  It is
-// CONSERVATIVE — rounding never culls a box the f64 narrow phase would hit: fm(plane, inv, noi) differs from
-// (plane − o)·inv by at most u·(|t| + |o·inv|) (the rounding of noi and of the fma), covered on the exit side by the
-// relative and the absolute slack (BoxSlack).  A direction component of 0 reaches here as ±1/K (bvh_begin): the axis
-// yields huge finite distances of the right sign — the whole line when o lies in the slab, nothing when it lies outside.
+// Slab test (AABB.hit, src/hit.zig:70-98) with 1/d and −o/d hoisted: each plane distance is one fma, and the test is
+// bare: t1 ≥ t0.  It is CONSERVATIVE — rounding never culls a box the f64 narrow phase would hit — because the BOX is
+// padded, not the comparison (round 3; rounds 1–2 paid a slack fma per box, a term Σ|noi| per segment and one more level
+// in the step's dependent chain).  With inv = (1/d)(1+e1), noi = −o·inv(1+e2) and the fma's own rounding e3, the distance
+// computed for a plane p is the EXACT distance of the true ray to a plane p' with
+//     p' − o = (1+e1)(1+e3)·[(p − o) − o·e2],     |p' − p| ≤ (|e1|+|e3|)|p − o| + |e2||o| (+ second order)
+// |e2|, |e3| ≤ u = 2^-24, |e1| ≤ u (R = float) or 2u (R = double: d_k narrowed to f32, then divided): |p' − p| ≤ 5.1u·(B + S)
+// for box coordinates |p| ≤ B and origins |o| ≤ S.  The host stores every box padded by E = 16u·max(S, B) ≥ that per side
+// (rayz_hip.hip: box_pad), so each computed slab interval contains the true box's exact one, for either sign of d_k.  A
+// direction component of 0 reaches here as ±1/K (bvh_begin): huge finite distances whose SIGN is right as long as the
+// origin is not within u·(|p − o| + |o|) < E of the plane — and a true ray that runs parallel to a slab is inside it only
+// if it is strictly between the TRUE planes, i.e. at least E inside the padded ones.
 // `tmin` is the caller's tmin rounded DOWN to f32, q.tb32 tbest rounded UP.  Returns the entry distance through `t0`.
 template <class R, bool kUniformTmin = false>
 __device__ __forceinline__ bool bvh_box_hit(f4 lo, f4 hi, const BvhQuery<R>& q, float tmin, float& t0) {
@@ -1116,7 +1117,7 @@ __device__ __forceinline__ bool bvh_box_hit(f4 lo, f4 hi, const BvhQuery<R>& q, 
     float tb;
     if constexpr (sizeof(R) == 4) tb = q.tbest; else tb = q.tb32; // (f32: tbest itself — no second register)
     const float t1 = mn(mn(mx(ax, bx), mx(ay, by)), min_bound(mx(az, bz), tb));
-    return fm(t1, BoxSlack<R>::rel, q.eb) >= t0;
+    return t1 >= t0;
 }
 
 // Phase N — one step of a lane that holds an inner node: fetch the node's record, slab-test both children, push the
@@ -1284,7 +1285,6 @@ template <class R> __global__ __launch_bounds__(256, bvh_waves<R>()) void trace_
     BvhQuery<R> q;
     q.inv = {1.0f, 1.0f, 1.0f};
     q.noi = {0.0f, 0.0f, 0.0f};
-    q.eb = 0.0f;
     q.tb32 = 0.0f;
     q.inv_a2 = 1.0;
     q.tbest = R(0);
@@ -1568,7 +1568,6 @@ template <class R> __global__ __launch_bounds__(256, RAYZ_BVH2_WAVES) void trace
     BvhQuery<R> q;
     q.inv = {1.0f, 1.0f, 1.0f};
     q.noi = {0.0f, 0.0f, 0.0f};
-    q.eb = 0.0f;
     q.tb32 = 0.0f;
     q.inv_a2 = 1.0;
     q.tbest = R(0);
@@ -1861,8 +1860,9 @@ template <class R> __global__ __launch_bounds__(64) void kat_kernel(uint32_t op,
         q.tb32 = round_up_f32(q.tbest);
         float t0;
         // the box as the device holds it: f32, rounded outward (host: bvh_build.hpp roundDown / roundUp)
-        const f4 lo = {__double2float_rd(a[0]), __double2float_rd(a[1]), __double2float_rd(a[2]), 0.0f};
-        const f4 hi = {__double2float_ru(a[3]), __double2float_ru(a[4]), __double2float_ru(a[5]), 0.0f};
+        // (.. padded by a[14] = E, which the host computes from the record as the scene upload would: rayz_hip_kat)
+        const f4 lo = {__double2float_rd(a[0] - a[14]), __double2float_rd(a[1] - a[14]), __double2float_rd(a[2] - a[14]), 0.0f};
+        const f4 hi = {__double2float_ru(a[3] + a[14]), __double2float_ru(a[4] + a[14]), __double2float_ru(a[5] + a[14]), 0.0f};
         r[0] = bvh_box_hit<R>(lo, hi, q, round_down_f32((R)a[12]), t0) ? 1.0 : 0.0;
         r[1] = (double)t0;
         break;

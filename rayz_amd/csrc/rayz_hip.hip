@@ -478,6 +478,11 @@ template <class R> int upload_bvh_body(RayzScene* s, SceneBuffers<R>& b) {
                 inner_order.push_back((uint32_t)i);
             }
     }
+    // the boxes go to the device padded: the slab test carries no slack of its own (rayz_device.hpp: bvh_box_hit)
+    double box_B = 0;
+    for (const rayz_bvh::FlatNode& n : t.nodes)
+        for (int k = 0; k < 3; ++k) box_B = std::max({box_B, std::fabs(n.box.lo[k]), std::fabs(n.box.hi[k])});
+    const double box_pad = kBoxPadUlps * unit_roundoff<float>() * std::max(b.pad_S, box_B);
     auto leaf_info = [&](const rayz_bvh::FlatNode& n) {
         uint32_t info = (n.first << 4) | n.count;
         for (uint32_t k = 0; k < n.count; ++k)
@@ -487,11 +492,11 @@ template <class R> int upload_bvh_body(RayzScene* s, SceneBuffers<R>& b) {
     auto child = [&](size_t c) {
         const rayz_bvh::FlatNode& n = t.nodes[c];
         const bool is_leaf = n.count != 0;
-        nodes.push_back(f4{rayz_bvh::roundDown<float>(n.box.lo[0]), rayz_bvh::roundDown<float>(n.box.lo[1]),
-                           rayz_bvh::roundDown<float>(n.box.lo[2]),
+        nodes.push_back(f4{rayz_bvh::roundDown<float>(n.box.lo[0] - box_pad), rayz_bvh::roundDown<float>(n.box.lo[1] - box_pad),
+                           rayz_bvh::roundDown<float>(n.box.lo[2] - box_pad),
                            Bits<float>::from(is_leaf ? (kBvhLeafFlag | leaf_info(n)) : (inner_index[c] << 6))}); // inner: byte offset
-        nodes.push_back(f4{rayz_bvh::roundUp<float>(n.box.hi[0]), rayz_bvh::roundUp<float>(n.box.hi[1]),
-                           rayz_bvh::roundUp<float>(n.box.hi[2]), 0.0f});
+        nodes.push_back(f4{rayz_bvh::roundUp<float>(n.box.hi[0] + box_pad), rayz_bvh::roundUp<float>(n.box.hi[1] + box_pad),
+                           rayz_bvh::roundUp<float>(n.box.hi[2] + box_pad), 0.0f});
     };
     if (!t.nodes.empty() && t.nodes[0].count != 0) { // the whole pool fits one leaf: a root record whose two child
         child(0);                                     // slots both name it (the repeat cannot change the result)
@@ -1444,6 +1449,11 @@ int rayz_hip_kat(uint32_t op, uint32_t precision, const double* in, uint32_t n, 
                 const double nu = a[at];
                 if (!(nu >= 0 && nu <= RAYZ_KAT_IN_STRIDE - (at + 1) && nu == std::floor(nu)))
                     return fail(RAYZ_ERR_BAD_ARG, "record %u: n_u = %g is not an integer in [0, %d]", i, nu, RAYZ_KAT_IN_STRIDE - (at + 1));
+            }
+            if (op == RAYZ_KAT_BOX_HIT) { // the padding the scene upload gives a box: S = this ray's origin, B = this box
+                double B = 0;
+                for (int k = 0; k < 6; ++k) B = std::max(B, std::fabs(a[k]));
+                a[14] = kBoxPadUlps * unit_roundoff<float>() * std::max(norm3(a + 6), B);
             }
             if (op == RAYZ_KAT_SCAN_DISCS) { // the padded squares the scan streams would hold for these four spheres
                 double S = norm3(a + 20);
