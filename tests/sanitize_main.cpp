@@ -12,6 +12,10 @@ extern "C" int rayz_hip_render(const RayzSceneDesc*, const RayzCameraDesc*, cons
 extern "C" int rayz_hip_render_f64(const RayzSceneDesc*, const RayzCameraDesc*, const RayzRenderParams*, double*, RayzRenderStats*) { return RAYZ_ERR_NO_DEVICE; }
 extern "C" int rayz_hip_render_multi(const int*, int, const RayzSceneDesc*, const RayzCameraDesc*, const RayzRenderParams*, float*, RayzRenderStats*) { return RAYZ_ERR_NO_DEVICE; }
 extern "C" int rayz_hip_render_multi_f64(const int*, int, const RayzSceneDesc*, const RayzCameraDesc*, const RayzRenderParams*, double*, RayzRenderStats*) { return RAYZ_ERR_NO_DEVICE; }
+extern "C" int rayz_hip_multi_create(const int*, int, const RayzSceneDesc*, uint32_t, RayzMulti** out) { if (out) *out = nullptr; return RAYZ_ERR_NO_DEVICE; }
+extern "C" int rayz_hip_multi_destroy(RayzMulti*) { return RAYZ_OK; }
+extern "C" int rayz_hip_multi_render(RayzMulti*, const RayzCameraDesc*, const RayzRenderParams*, float*, RayzRenderStats*) { return RAYZ_ERR_NO_DEVICE; }
+extern "C" int rayz_hip_multi_render_f64(RayzMulti*, const RayzCameraDesc*, const RayzRenderParams*, double*, RayzRenderStats*) { return RAYZ_ERR_NO_DEVICE; }
 extern "C" const char* rayz_hip_last_error(void) { return "no device in the sanitizer build"; }
 
 static int run(rayz::Tracer& t, const char* name) {
