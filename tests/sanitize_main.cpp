@@ -63,6 +63,23 @@ int main() {
     bad |= run(t3, "triangleMesh");
     rayz::Tracer t4 = rayz::Tracer::init(24, 30, 1, 0, rayz::V3{0, 0, 2}, rayz::V3{}, rayz::V3::y_hat(), &seed);
     bad |= run(t4, "empty pool");
+    { // which hittables the walked tree keeps OUT of it (bvh_build.hpp, peel_oversized): an outlier only
+        rayz::Tracer rb = rayz::randomBouncing(48, -11, 11, &seed);
+        const rayz::Tracer::Flat fr = rb.flatten();
+        const rayz_bvh::FlatBvh peeled = rayz_bvh::build(fr.spheres, fr.triangles, true);
+        const bool ground_only = peeled.big.size() == 1 && fr.spheres[peeled.big[0]].radius == 1000.0; // src/rayz.zig:58-74
+        // a compact cluster of 40 similar spheres, each a good part of the cluster's extent: nothing is an outlier
+        std::vector<RayzSphere> cl(40);
+        for (size_t i = 0; i < cl.size(); ++i) {
+            cl[i] = RayzSphere{};
+            cl[i].center[0] = 0.9 * (double)(i % 4), cl[i].center[1] = 0.9 * (double)((i / 4) % 4), cl[i].center[2] = 0.9 * (double)(i / 16);
+            cl[i].radius = 0.5 + 0.01 * (double)i;
+        }
+        const rayz_bvh::FlatBvh cluster = rayz_bvh::build(cl, {}, true);
+        std::printf("peel: randomBouncing keeps %zu out (ground: %d), compact cluster keeps %zu out\n", peeled.big.size(), (int)ground_only,
+                    cluster.big.size());
+        bad |= !ground_only || !cluster.big.empty() || cluster.order.size() != cl.size();
+    }
     FILE* f = std::fopen("/dev/null", "w");
     t1.img.writePPM(f);
     std::fclose(f);
