@@ -287,15 +287,12 @@ def run(args, json_fd):
         frame_segments = float(segs.item())
         # per-rank figures, so that load imbalance between the row shards can be read off the line: every rank's mean trace-kernel
         # time and mean gather time (its own tile ready -> frame assembled: transfer + waiting for the slowest rank)
-        mine = torch.tensor([float(np.mean(kernel_ms)), float(np.mean(gather_ms)), float(np.mean(seg_total))], dtype=torch.float64, device=dev)
-        allr = torch.empty((world, 3), dtype=torch.float64, device=dev)
-        dist.all_gather_into_tensor(allr, mine)
-        per_rank = allr.cpu().numpy()
+        per_rank = rdist.rank_stats([np.mean(kernel_ms), np.mean(gather_ms), np.mean(seg_total)], dev, world)
         kernel_ms_avg = float(per_rank[:, 0].max())
     else:
         frame_segments = float(np.mean(seg_total))
         kernel_ms_avg = float(np.mean(kernel_ms))
-        per_rank = np.array([[kernel_ms_avg, float(np.mean(gather_ms)), frame_segments]])
+        per_rank = rdist.rank_stats([kernel_ms_avg, np.mean(gather_ms), frame_segments], dev, 1)
     # outside the timed region: the gathered frame must be a usable image (every rank holds all of it)
     if not bool(torch.isfinite(fg.frame).all().item()) or bool((fg.frame < 0).any().item()):
         raise SystemExit("bench.py: the rendered frame holds non-finite or negative radiance")
@@ -524,14 +521,7 @@ def run(args, json_fd):
                 "scalar_cache_bytes": lane_bytes / 64, "scalar_cache_TBps": lane_bytes / 64 / (kernel_ms_avg * 1e-3) / 1e12,
             }
         # every rank's own figures (N > 1: load imbalance between the row shards and the cost of the gather show here)
-        out["per_rank"] = {
-            "kernel_ms": {"min": float(per_rank[:, 0].min()), "mean": float(per_rank[:, 0].mean()), "max": float(per_rank[:, 0].max()),
-                          "all": [float(x) for x in per_rank[:, 0]]},
-            "gather_ms": {"min": float(per_rank[:, 1].min()), "mean": float(per_rank[:, 1].mean()), "max": float(per_rank[:, 1].max()),
-                          "note": "a rank's own tile traced -> frame assembled on that rank: the all_gather (transfer + waiting for the "
-                                  "slowest rank) + the un-interleave; N = 1: a device copy"},
-            "segments": [float(x) for x in per_rank[:, 2]],
-        }
+        out["per_rank"] = rdist.per_rank_block(per_rank)
         if also:
             out["also"] = also
         if not args.no_cpu_baseline and world == 1:

@@ -75,3 +75,27 @@ class FrameGather:
         for r in range(self.world):
             self.frame.index_copy_(0, self._idx[r], parts[r, : len(self.rows[r])])
         return self.frame
+
+
+def rank_stats(values, device, world: int, group=None) -> np.ndarray:
+    """Every rank's row of per-rank figures on every rank: one all_gather of a short f64 vector -> (world, len(values)).
+    bench.py reports each rank's mean trace-kernel time, gather time and segment count with it, so that load imbalance
+    between the row shards shows in the N > 1 line (the same code runs on gloo in the CPU tests)."""
+    mine = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    if world == 1:
+        return mine.cpu().numpy()[None, :]
+    out = torch.empty(world * mine.numel(), dtype=torch.float64, device=device)  # concatenated: the form RCCL AND gloo accept
+    dist.all_gather_into_tensor(out, mine, group=group)
+    return out.view(world, mine.numel()).cpu().numpy()
+
+
+def per_rank_block(per_rank: np.ndarray) -> dict:
+    """bench.py's `per_rank` object from rank_stats' table (columns: kernel ms, gather ms, segments)."""
+    k, g = per_rank[:, 0], per_rank[:, 1]
+    return {
+        "kernel_ms": {"min": float(k.min()), "mean": float(k.mean()), "max": float(k.max()), "all": [float(x) for x in k]},
+        "gather_ms": {"min": float(g.min()), "mean": float(g.mean()), "max": float(g.max()),
+                      "note": "a rank's own tile traced -> frame assembled on that rank: the all_gather (transfer + waiting for the "
+                              "slowest rank) + the un-interleave; N = 1: a device copy"},
+        "segments": [float(x) for x in per_rank[:, 2]],
+    }

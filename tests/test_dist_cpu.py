@@ -79,6 +79,12 @@ def _worker(rank, world, port, tile_rows, q):
         if rank == 0:
             full, _ = oracle.render_b(sd, cam, p, threads=1)
             q.put(bool(np.array_equal(frame, full)))
+        # the per-rank figures of bench.py's N > 1 line: every rank gets every rank's row
+        table = rdist.rank_stats([10.0 + rank, 0.5 * (rank + 1), 1000.0 * (rank + 1)], torch.device("cpu"), world)
+        assert table.shape == (world, 3) and table[:, 0].tolist() == [10.0 + r for r in range(world)]
+        blk = rdist.per_rank_block(table)
+        assert blk["kernel_ms"]["max"] == 10.0 + world - 1 and blk["kernel_ms"]["min"] == 10.0 and len(blk["kernel_ms"]["all"]) == world
+        assert blk["gather_ms"]["mean"] == 0.5 * (world + 1) / 2 and blk["segments"] == [1000.0 * (r + 1) for r in range(world)]
         # every rank holds the whole frame
         chk = torch.tensor([float(frame.sum())], dtype=torch.float64)
         lst = [torch.zeros_like(chk) for _ in range(world)]
