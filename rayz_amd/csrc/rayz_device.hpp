@@ -979,6 +979,19 @@ template <class R, int NR> __global__ __launch_bounds__(256, (flat_waves<R, NR>(
 // The reference recurses left-then-right with a shrinking tmax.  Here each lane walks the same tree with a small
 // stack (LDS) and visits the NEARER child first; the nearest hit and its tie rule do not depend on visiting
 // order, so the result is the reference's.  Per-lane state of one query:
+// Threads per workgroup of the one-path BVH kernel = stride of its LDS stacks.  1,024 = ONE workgroup per CU (16 waves, 4
+// per SIMD as before), so that ONE copy of the tree's top serves the whole CU and can take all the LDS the stacks leave:
+// ≈1,300 inner-node records for config 3 instead of 256 per 256-thread workgroup.  The walk's shared bottleneck is the
+// vector-memory address pipe (TA_TA_BUSY 84 %: every step gathers 64 B per lane, 4 divergent dwordx4 loads); a node read
+// from LDS does not go through it.  config 3: 42 % of the lane-steps are served by a 256-record top, 55 % by 1,280
+// (profiles/r03/lds_top/): 3,554 instead of 3,366 Msamples/s; same speed as 256-thread workgroups at equal top size.
+#ifndef RAYZ_BVH_WG
+#define RAYZ_BVH_WG 1024
+#endif
+constexpr uint32_t kBvhWg = RAYZ_BVH_WG, kBvh2Wg = 256; // (the two-path kernel needs 168 VGPRs: 256-thread workgroups, 3 per CU)
+// LDS a BVH workgroup may ask for: hipFuncSetAttribute(MaxDynamicSharedMemorySize) refuses requests near the CU's 160 KB
+// (151,552 B accepted, 155,648 B refused on this stack), so the top of the tree is sized for 150 KB in all
+constexpr size_t kBvhLdsBudget = 150 * 1024;
 constexpr int kBvhStackDepth = 28;            // ≥ tree depth: median split gives ceil(log2(n / 2)) + 1 (n ≤ 2^27)
 constexpr uint32_t kBvhDone = 0x7fffffffu;     // cursor: nothing left to visit (positive: not a leaf reference)
 constexpr uint32_t kBvhLeafFlag = 0x80000000u; // child reference / stack entry is a leaf descriptor, not an inner index
@@ -1126,7 +1139,7 @@ __device__ __forceinline__ bool bvh_box_hit(f4 lo, f4 hi, const BvhQuery<R>& q, 
 // parked for phase L, kBvhDone (the sentinel under the stack) → walk complete.  Branch-free: the push lands above the
 // top when there is nothing to push, the pop is a read every stepping lane makes.  `stack` is this lane's column of
 // the workgroup's LDS stack (entry s at stack[s * 256]).
-template <class R>
+template <class R, uint32_t WG>
 __device__ __forceinline__ void bvh_node_step(const DevScene<R>& sc, const f4* nodes_base, BvhQuery<R>& q, float tmin, uint32_t* stack
 #ifdef RAYZ_BVH_PROFILE
                                               , unsigned long long& g_fetch_ticks
@@ -1179,20 +1192,20 @@ __device__ __forceinline__ void bvh_node_step(const DevScene<R>& sc, const f4* n
     // (a child that was not hit may ride along as `near` or `far`: `none` and `both` decide what is used)
     const uint32_t l = bits(llo.w), r = bits(rlo.w);
     const uint32_t near = mask_select(swap, r, l), far = mask_select(swap, l, r);
-    stack[256 * (q.sp + 1u)] = far; // lands above the top unless both were hit
+    stack[WG * (q.sp + 1u)] = far; // lands above the top unless both were hit
     const uint32_t sp = mask_add(q.sp, both);
     q.cur = mask_select(none, q.top, near); // nothing hit => nothing pushed: the entry read ahead IS the top
     q.sp = mask_sub(sp, none); // popping the sentinel leaves sp at −1: the lane holds kBvhDone and steps no more until
                                // bvh_begin (its read-ahead below lands in the guard row under the stack)
-    q.top = stack[256 * q.sp]; // read ahead for the NEXT pop — after the store above (LDS keeps a wave's order), consumed
+    q.top = stack[WG * q.sp]; // read ahead for the NEXT pop — after the store above (LDS keeps a wave's order), consumed
                                // one step later, behind that step's node fetch: its latency is off the critical path
 }
 
 // The next entry of a lane that is done with its parked leaf.
-template <class R> __device__ __forceinline__ void bvh_pop(BvhQuery<R>& q, const uint32_t* stack) {
+template <class R, uint32_t WG> __device__ __forceinline__ void bvh_pop(BvhQuery<R>& q, const uint32_t* stack) {
     q.cur = q.top;
     q.sp -= 1u;
-    q.top = stack[256 * q.sp];
+    q.top = stack[WG * q.sp];
 }
 
 // The reject test of a leaf entry (general velocity form of DESIGN.md §4.3, f32 for both precisions): the ONE place it is
@@ -1274,7 +1287,8 @@ constexpr int kBvhKeepStepping = 16; // phase N continues while at least this ma
 #define RAYZ_BVH_WAVES_F64 4 // 151 and ran 3 waves per SIMD before: +13 % from the fourth)
 #endif
 template <class R> constexpr int bvh_waves() { return sizeof(R) == 8 ? RAYZ_BVH_WAVES_F64 : RAYZ_BVH_WAVES; }
-template <class R> __global__ __launch_bounds__(256, bvh_waves<R>()) void trace_kernel_bvh(const TraceArgs<R> A) {
+template <class R> __global__ __launch_bounds__(RAYZ_BVH_WG, (bvh_waves<R>() * 256 >= RAYZ_BVH_WG ? bvh_waves<R>() * 256 / RAYZ_BVH_WG : 1))
+void trace_kernel_bvh(const TraceArgs<R> A) {
     typedef typename VecOf<R>::type r4;
     const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     const uint32_t n_nodes = A.sc.bvh_n_nodes;
@@ -1304,8 +1318,8 @@ template <class R> __global__ __launch_bounds__(256, bvh_waves<R>()) void trace_
         return;
     }
     f4* top = (f4*)lds_words;
-    uint32_t* stack = lds_words + A.bvh_top_words + 256u + threadIdx.x; // (one guard row under entry 0: BvhQuery::top)
-    for (uint32_t k = threadIdx.x; k < A.sc.bvh_top / 16u; k += 256u) top[k] = A.sc.bvh_nodes[k];
+    uint32_t* stack = lds_words + A.bvh_top_words + kBvhWg + threadIdx.x; // (one guard row under entry 0: BvhQuery::top)
+    for (uint32_t k = threadIdx.x; k < A.sc.bvh_top / 16u; k += kBvhWg) top[k] = A.sc.bvh_nodes[k];
     stack[0] = kBvhDone; // the sentinel under every lane's stack
     __syncthreads();
     R time = 0;
@@ -1399,16 +1413,16 @@ template <class R> __global__ __launch_bounds__(256, bvh_waves<R>()) void trace_
                 px3[0] += __popcll(__ballot((int32_t)q.cur < 0));
                 px3[1] += __popcll(__ballot(alive && q.cur == kBvhDone));
                 px3[2] += __popcll(__ballot(!alive));
-                if (can_step) bvh_node_step<R>(A.sc, A.sc.bvh_nodes, q, tmin32, stack, fetch_ticks);
+                if (can_step) bvh_node_step<R, kBvhWg>(A.sc, A.sc.bvh_nodes, q, tmin32, stack, fetch_ticks);
 #else
-                if (can_step) bvh_node_step<R>(A.sc, A.sc.bvh_nodes, q, tmin32, stack);
+                if (can_step) bvh_node_step<R, kBvhWg>(A.sc, A.sc.bvh_nodes, q, tmin32, stack);
                 // .. and a second step for the lanes that still hold an inner node, without a new wave-level decision (lane
                 // counts against thresholds are scalar work with a taken branch at its end: every other step is enough —
                 // +1 % on configs 3 / 5, +2.6 % on config 2, profiles/r03/bvh_step/unroll.log; three or four lose it again)
                 {
                     const bool again = q.cur < kBvhDone;
                     node_tests += 2u * (uint32_t)__popcll(__ballot(again));
-                    if (again) bvh_node_step<R>(A.sc, A.sc.bvh_nodes, q, tmin32, stack);
+                    if (again) bvh_node_step<R, kBvhWg>(A.sc, A.sc.bvh_nodes, q, tmin32, stack);
                 }
 #endif
                 node_tests += 2u * (uint32_t)n_can;
@@ -1423,7 +1437,7 @@ template <class R> __global__ __launch_bounds__(256, bvh_waves<R>()) void trace_
                 sphere_tests += leaf & 3u;
                 cand0 = bvh_leaf_entry<R>(A.sc, q, leaf, 0u, o, d, ud, time, A.tmin);
                 if ((leaf & 3u) > 1u) cand1 = bvh_leaf_entry<R>(A.sc, q, leaf, 1u, o, d, ud, time, A.tmin);
-                bvh_pop<R>(q, stack);
+                bvh_pop<R, kBvhWg>(q, stack);
             }
             RAYZ_PROF_T(2)
             if (__ballot((cand0 | cand1) != 0u) != 0ull) { // phase C
@@ -1723,9 +1737,9 @@ template <class R> __global__ __launch_bounds__(256, RAYZ_BVH2_WAVES) void trace
                 px3[0] += __popcll(__ballot((int32_t)q.cur < 0));
                 px3[1] += __popcll(__ballot(q.cur == kBvhDone));
                 unsigned long long ft_ = 0;
-                if (can_step) bvh_node_step<R>(A.sc, nodes_base, q, tmin32, stack, ft_);
+                if (can_step) bvh_node_step<R, kBvh2Wg>(A.sc, nodes_base, q, tmin32, stack, ft_);
 #else
-                if (can_step) bvh_node_step<R>(A.sc, nodes_base, q, tmin32, stack);
+                if (can_step) bvh_node_step<R, kBvh2Wg>(A.sc, nodes_base, q, tmin32, stack);
 #endif
                 node_tests += 2u * (uint32_t)n_can;
             }
@@ -1739,7 +1753,7 @@ template <class R> __global__ __launch_bounds__(256, RAYZ_BVH2_WAVES) void trace
                     sphere_tests += leaf & 3u;
                     cand0 = bvh_leaf_entry<R>(A.sc, q, leaf, 0u, o, d, ud, time, A.tmin);
                     if ((leaf & 3u) > 1u) cand1 = bvh_leaf_entry<R>(A.sc, q, leaf, 1u, o, d, ud, time, A.tmin);
-                    bvh_pop<R>(q, stack);
+                    bvh_pop<R, kBvh2Wg>(q, stack);
                 }
                 RAYZ_PROF2_T(3)
                 if (__ballot((cand0 | cand1) != 0u) != 0ull) { // phase C

@@ -461,7 +461,11 @@ template <class R> int upload_bvh_body(RayzScene* s, SceneBuffers<R>& b) {
     std::vector<uint32_t> inner_index(t.nodes.size(), 0xffffffffu), inner_order;
     uint32_t n_inner = 0;
     {
-        const uint32_t top_cap = (uint32_t)tuning(RAYZ_DEBUG_BVH_TOP, 256); // top-of-tree records kept in LDS
+        // top-of-tree records kept in LDS: as many as fit beside the stacks of the one-path kernel's workgroup (the two-path
+        // kernel, with its smaller workgroups, keeps a prefix of them); RAYZ_DEBUG_BVH_TOP lowers the cap
+        const size_t stacks = ((size_t)t.depth + 3) * kBvhWg * sizeof(uint32_t);
+        const uint32_t fit = stacks < kBvhLdsBudget ? (uint32_t)((kBvhLdsBudget - stacks) / 64) : 0u;
+        const uint32_t top_cap = (uint32_t)std::min<long long>(tuning(RAYZ_DEBUG_BVH_TOP, fit), fit);
         std::vector<size_t> frontier;
         if (!t.nodes.empty() && t.nodes[0].count == 0) frontier.push_back(0);
         for (size_t head = 0; head < frontier.size() && n_inner < top_cap; ++head) {
@@ -777,7 +781,7 @@ int render_impl(RayzScene* s, const DeviceCtx& ctx, SceneBuffers<R>& b, const Ra
     A.sc.bvh_leaf_stride = b.bvh_leaf_stride;
     A.sc.bvh_n_big_leaves = use_bvh ? b.n_big_leaves : 0u;
     for (int k = 0; k < 4; ++k) A.sc.bvh_big[k] = b.big_desc[k];
-    A.sc.bvh_top = use_bvh ? b.bvh_top * 64u : 0u; // bytes (the walk compares byte offsets)
+    A.sc.bvh_top = 0u; // (bytes: set below, once the launch knows how many records its workgroup keeps in LDS)
     fill_camera<R>(cam, A.cam);
     A.partial = (r4*)s->partial;
     A.counters = s->counters;
@@ -804,16 +808,25 @@ int render_impl(RayzScene* s, const DeviceCtx& ctx, SceneBuffers<R>& b, const Ra
     else
         A.bvh_keep = (uint32_t)tuning(RAYZ_DEBUG_BVH_KEEP, kBvhKeepActive | (kBvhKeepStepping << 8));
 
-    const int block = 256;
+    const int block = (use_bvh && !two_paths) ? (int)kBvhWg : 256;
     int blocks_per_cu = 0;
     // the BVH kernel's LDS stack holds one entry per tree level below the root (nearer child first: the stack never
     // holds more than one entry per level); sized from THIS tree, so a shallow tree does not cap the occupancy
     // (+ one guard row under entry 0: a lane that has popped its sentinel reads ahead at index −1)
     const size_t bvh_stack_bytes = use_bvh ? ((size_t)s->bvh_dev.depth + 3) * block * sizeof(uint32_t) : 0;
-    const size_t bvh_top_bytes = use_bvh ? (size_t)b.bvh_top * 4 * sizeof(f4) : 0; // the tree's top: first in LDS
+    // the tree's top: first in LDS.  The scene numbered b.bvh_top records breadth-first for the one-path kernel's workgroup;
+    // a kernel whose workgroup has less LDS to spare (two paths per lane: three 256-thread workgroups per CU) keeps a prefix
+    uint32_t top_records = use_bvh ? b.bvh_top : 0u;
+    if (two_paths) top_records = std::min<uint32_t>(top_records, 256u);
+    const size_t bvh_top_bytes = (size_t)top_records * 4 * sizeof(f4);
     // (+ RAYZ_DEBUG_LDS_PAD unused bytes: an occupancy experiment — fewer workgroups per CU, the same code)
     const size_t bvh_lds = bvh_top_bytes + bvh_stack_bytes + (use_bvh ? (size_t)tuning(RAYZ_DEBUG_LDS_PAD, 0) : 0);
     A.bvh_top_words = (uint32_t)(bvh_top_bytes / sizeof(uint32_t));
+    A.sc.bvh_top = (uint32_t)bvh_top_bytes; // the walk compares byte offsets
+    if (use_bvh && bvh_lds > 64 * 1024) { // a workgroup that asks for more than 64 KB of LDS has to say so first
+        if (two_paths) HIP_TRY(hipFuncSetAttribute((const void*)trace_kernel_bvh2<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bvh_lds));
+        else HIP_TRY(hipFuncSetAttribute((const void*)trace_kernel_bvh<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bvh_lds));
+    }
     if (two_paths) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, trace_kernel_bvh2<float>, block, bvh_lds));
     else if (use_bvh) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, trace_kernel_bvh<R>, block, bvh_lds));
     else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, trace_kernel<R, 1>, block, 0));
