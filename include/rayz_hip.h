@@ -185,11 +185,12 @@ typedef enum RayzDebugKnob {
     RAYZ_DEBUG_QUEUE_GRAB = 0, /* work items a wave reserves per atomic on the queue head (default 64) */
     RAYZ_DEBUG_BVH_KEEP = 1,   /* one-path BVH kernel: keep_active | keep_stepping << 8 */
     RAYZ_DEBUG_BVH_PEEL = 2,   /* 0: walk the reference's full tree (oversized hittables stay in it) */
-    RAYZ_DEBUG_BVH_TOP = 3,    /* inner-node records of the tree's top kept in LDS (default 256) */
+    RAYZ_DEBUG_BVH_TOP = 3,    /* cap on the inner-node records of the tree's top kept in LDS (default: what fits beside the stacks) */
     RAYZ_DEBUG_BVH_KERNEL = 4, /* f32 BVH renders: 1 = one path per lane (trace_kernel_bvh, default), 2 = two (trace_kernel_bvh2) */
     RAYZ_DEBUG_BVH2_KEEP = 5,  /* two-path BVH kernel: service | blocked << 8 | swap << 16 | keep_stepping << 24 */
     RAYZ_DEBUG_LDS_PAD = 6,    /* BVH kernels: unused bytes added to the workgroup's LDS request (occupancy experiments) */
-    RAYZ_DEBUG_KNOBS = 7
+    RAYZ_DEBUG_BVH_TOP_ORDER = 7, /* which inner nodes the LDS top holds: 0 = by box surface area from the root (default), 1 = breadth-first */
+    RAYZ_DEBUG_KNOBS = 8
 } RayzDebugKnob;
 int rayz_hip_debug_set(uint32_t knob, long long value);
 

@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <atomic>
 #include <new>
+#include <queue>
 #include <type_traits>
 #include <vector>
 
@@ -456,8 +457,7 @@ template <class R> int upload_bvh_body(RayzScene* s, SceneBuffers<R>& b) {
     // (first << 4 | type1 << 3 | type0 << 2 | count)
     std::vector<f4> nodes;
     std::vector<r4> leaf;
-    // inner nodes are numbered breadth-first for the first kBvhTopNodes (the top levels, which the kernel keeps in LDS),
-    // the rest in pre-order
+    // the inner nodes the kernel keeps in LDS (the tree's "top") are numbered first, the rest in pre-order
     std::vector<uint32_t> inner_index(t.nodes.size(), 0xffffffffu), inner_order;
     uint32_t n_inner = 0;
     {
@@ -466,14 +466,26 @@ template <class R> int upload_bvh_body(RayzScene* s, SceneBuffers<R>& b) {
         const size_t stacks = ((size_t)t.depth + 3) * kBvhWg * sizeof(uint32_t);
         const uint32_t fit = stacks < kBvhLdsBudget ? (uint32_t)((kBvhLdsBudget - stacks) / 64) : 0u;
         const uint32_t top_cap = (uint32_t)std::min<long long>(tuning(RAYZ_DEBUG_BVH_TOP, fit), fit);
-        std::vector<size_t> frontier;
-        if (!t.nodes.empty() && t.nodes[0].count == 0) frontier.push_back(0);
-        for (size_t head = 0; head < frontier.size() && n_inner < top_cap; ++head) {
-            const size_t i = frontier[head];
+        // WHICH records: grown from the root, always taking the candidate whose box has the largest surface area next — the
+        // chance that a ray visits a node goes with its box's area, and never exceeds its parent's (RAYZ_DEBUG_BVH_TOP_ORDER
+        // = 1: plain breadth-first, the order of rounds 2-3a)
+        auto area = [&](size_t i) {
+            const rayz_bvh::Box& x = t.nodes[i].box;
+            const double dx = x.hi[0] - x.lo[0], dy = x.hi[1] - x.lo[1], dz = x.hi[2] - x.lo[2];
+            return dx * dy + dy * dz + dz * dx;
+        };
+        const bool by_area = tuning(RAYZ_DEBUG_BVH_TOP_ORDER, 0) == 0;
+        typedef std::pair<double, size_t> Cand; // (priority, node): largest first; breadth-first = decreasing sequence numbers
+        std::priority_queue<Cand> frontier;
+        double seq = 0;
+        if (!t.nodes.empty() && t.nodes[0].count == 0) frontier.push({by_area ? area(0) : seq--, 0});
+        while (!frontier.empty() && n_inner < top_cap) {
+            const size_t i = frontier.top().second;
+            frontier.pop();
             inner_index[i] = n_inner++;
             inner_order.push_back((uint32_t)i);
             for (size_t c : {i + 1, (size_t)t.nodes[i + 1].skip})
-                if (t.nodes[c].count == 0) frontier.push_back(c);
+                if (t.nodes[c].count == 0) frontier.push({by_area ? area(c) : seq--, c});
         }
         b.bvh_top = n_inner;
         for (size_t i = 0; i < t.nodes.size(); ++i)
