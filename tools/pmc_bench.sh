@@ -19,3 +19,4 @@ run bvh_pmc_wait --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE
 run bvh_pmc_mem --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum
 run bvh_pmc_fetch --pmc FETCH_SIZE
 run bvh_pmc_write --pmc WRITE_SIZE
+run bvh_pmc_ta --pmc TA_TA_BUSY_sum TA_BUSY_avr GRBM_GUI_ACTIVE
