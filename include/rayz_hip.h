@@ -190,7 +190,8 @@ typedef enum RayzDebugKnob {
     RAYZ_DEBUG_BVH2_KEEP = 5,  /* two-path BVH kernel: service | blocked << 8 | swap << 16 | keep_stepping << 24 */
     RAYZ_DEBUG_LDS_PAD = 6,    /* BVH kernels: unused bytes added to the workgroup's LDS request (occupancy experiments) */
     RAYZ_DEBUG_BVH_TOP_ORDER = 7, /* which inner nodes the LDS top holds: 0 = by box surface area from the root (default), 1 = breadth-first */
-    RAYZ_DEBUG_KNOBS = 8
+    RAYZ_DEBUG_BVH_NODES = 8,     /* node record format of trees built from now on: 0 = by tree size (default), 1 = f32 planes (64 B), 2 = 16-bit plane indices (32 B) */
+    RAYZ_DEBUG_KNOBS = 9
 } RayzDebugKnob;
 int rayz_hip_debug_set(uint32_t knob, long long value);
 
@@ -317,7 +318,8 @@ typedef enum RayzKatOp {
                                      n_u[21] (an integer in [0, 26], RAYZ_ERR_BAD_ARG otherwise) u[22..]; n_u = 0 is NOT
                                      getRay(px,py,null): the kernel always draws
                                  out: origin[0..2] dir[3..5] time[6] draws[7]                           src/camera.zig:59-90 */
-    RAYZ_KAT_BOX_HIT = 3,     /* in: low[0..2] high[3..5] origin[6..8] dir[9..11] tmin[12] tmax[13]
+    RAYZ_KAT_BOX_HIT = 3,     /* in: low[0..2] high[3..5] origin[6..8] dir[9..11] tmin[12] tmax[13] format[26] (the node record
+                                     the box is tested in: 0 = 16-bit plane indices, non-zero = f32 planes)
                                  out: hit[0] t_entry[1]                                                 src/hit.zig:70-98 */
     RAYZ_KAT_SPHERE_HIT = 4,  /* in: center[0..2] velocity[3..5] radius[6] origin[7..9] dir[10..12] time[13] tmin[14] tmax[15]
                                  out: hit[0] t[1] point[2..4] normal[5..7] front_face[8] passed_filter[9]

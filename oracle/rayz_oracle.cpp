@@ -1373,14 +1373,61 @@ template <class R> static void katB(uint32_t op, const double* a, double* r) {
         break;
     }
     case RAYZ_KAT_BOX_HIT: {
+        // the box test of the DEVICE walk, restated: the box as 16-bit plane indices on a grid over it (lower planes the
+        // largest index at or below plane − E, upper ones the smallest at or above plane + E, E = 16u·(max(S, B) + X), S = this
+        // ray's origin, B = this box, X = the grid's extent), each plane distance fm(float(index), cell·inv, fm(glo, inv, −o·inv)),
+        // hit iff t1 ≥ t0.  (Mode B's own walk tests padded f32 boxes — boxHit above; the image depends on neither.)
+        // a[26] != 0: the other record format — the box padded by E = 16u·max(S, B) and rounded outward to f32 (as mode B's
+        // own walk holds its boxes)
         const SlabRay<R> slab = slabRay<R>(v3(6), v3(9));
-        double Bk = 0; // the box as the device holds it: padded for S = this ray's origin, B = this box, rounded outward
+        double Bk = 0;
         for (int k = 0; k < 6; ++k) Bk = std::max(Bk, std::fabs(a[k]));
-        const double pad = boxPad(norm3(a + 6), Bk);
-        const float lo[3] = {roundDown<float>(a[0] - pad), roundDown<float>(a[1] - pad), roundDown<float>(a[2] - pad)};
-        const float hi[3] = {roundUp<float>(a[3] + pad), roundUp<float>(a[4] + pad), roundUp<float>(a[5] + pad)};
-        float t0;
-        r[0] = boxHit<R>(lo, hi, slab, (R)a[12], (R)a[13], t0) ? 1.0 : 0.0;
+        if (a[26] != 0.0) {
+            const double pad = boxPad(norm3(a + 6), Bk);
+            const float lo[3] = {roundDown<float>(a[0] - pad), roundDown<float>(a[1] - pad), roundDown<float>(a[2] - pad)};
+            const float hi[3] = {roundUp<float>(a[3] + pad), roundUp<float>(a[4] + pad), roundUp<float>(a[5] + pad)};
+            float t0;
+            r[0] = boxHit<R>(lo, hi, slab, (R)a[12], (R)a[13], t0) ? 1.0 : 0.0;
+            r[1] = (double)t0;
+            break;
+        }
+        const double u = std::numeric_limits<float>::epsilon() / 2.0;
+        double pad = kBoxPadUlps * u * (std::max(norm3(a + 6), Bk) + 2.0 * Bk);
+        float glo[3], cell[3];
+        double extent = 0;
+        for (int k = 0; k < 3; ++k) { // the grid over [lo − 2 pad, hi + 2 pad]: 65,535 cells, the cell size rounded up until the last plane reaches
+            const double ga = a[k] - 2.0 * pad, gb = a[3 + k] + 2.0 * pad;
+            float f = roundDown<float>(ga);
+            float c = (float)((gb - (double)f) / 65535.0);
+            if (!(c > 0.0f)) c = std::numeric_limits<float>::min();
+            while ((double)f + 65535.0 * (double)c < gb) c = std::nextafter(c, std::numeric_limits<float>::infinity());
+            glo[k] = f, cell[k] = c;
+            extent = std::max(extent, 65535.0 * (double)c);
+        }
+        pad = kBoxPadUlps * u * (std::max(norm3(a + 6), Bk) + extent);
+        auto plane = [&](int k, double i) { return (double)glo[k] + i * (double)cell[k]; };
+        float qlo[3], qhi[3];
+        for (int k = 0; k < 3; ++k) {
+            double i = std::min(65535.0, std::max(0.0, std::floor((a[k] - pad - (double)glo[k]) / (double)cell[k])));
+            while (i > 0 && plane(k, i) > a[k] - pad) i -= 1;
+            while (i < 65535 && plane(k, i + 1) <= a[k] - pad) i += 1;
+            qlo[k] = (float)i;
+            double j = std::min(65535.0, std::max(0.0, std::ceil((a[3 + k] + pad - (double)glo[k]) / (double)cell[k])));
+            while (j < 65535 && plane(k, j) < a[3 + k] + pad) j += 1;
+            while (j > 0 && plane(k, j - 1) >= a[3 + k] + pad) j -= 1;
+            qhi[k] = (float)j;
+        }
+        const float inv[3] = {slab.inv.x, slab.inv.y, slab.inv.z}, noi[3] = {slab.noi.x, slab.noi.y, slab.noi.z};
+        float tn[3], tf[3];
+        for (int k = 0; k < 3; ++k) {
+            const float qa = cell[k] * inv[k], qb = fm(glo[k], inv[k], noi[k]);
+            const float ta = fm(qlo[k], qa, qb), tb = fm(qhi[k], qa, qb);
+            tn[k] = std::fmin(ta, tb), tf[k] = std::fmax(ta, tb);
+        }
+        const float tmin32 = roundDown<float>((double)(R)a[12]), tb32 = roundUp<float>((double)(R)a[13]);
+        const float t0 = std::fmax(std::fmax(tn[0], tn[1]), std::fmax(tn[2], tmin32));
+        const float t1 = std::fmin(std::fmin(tf[0], tf[1]), std::fmin(tf[2], tb32));
+        r[0] = t1 >= t0 ? 1.0 : 0.0;
         r[1] = (double)t0;
         break;
     }

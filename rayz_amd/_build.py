@@ -41,7 +41,7 @@ def _stale(target: str, sources: list[str]) -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     lib_src = [os.path.join(CSRC, "rayz_hip.hip"), os.path.join(HOST, "rayz_host.cpp")]
     deps = lib_src + [
-        os.path.join(CSRC, "rayz_device.hpp"), os.path.join(HOST, "rayz.hpp"),
+        os.path.join(CSRC, "rayz_device.hpp"), os.path.join(CSRC, "bvh_build.hpp"), os.path.join(HOST, "rayz.hpp"),
         os.path.join(ROOT, "include", "rayz_hip.h"), os.path.join(ROOT, "include", "rayz_host.h"),
         os.path.abspath(__file__),
     ]

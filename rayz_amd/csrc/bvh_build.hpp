@@ -152,6 +152,53 @@ inline FlatBvh build(const std::vector<RayzSphere>& spheres, const std::vector<R
     return out;
 }
 
+// ---- the boxes as the device holds them: 16-bit plane indices on a scene-wide grid ------------------------------------
+// plane(i) = glo[k] + i·cell[k] with glo, cell f32 (products of a 16-bit index and a 24-bit mantissa are exact in f64).  A
+// lower plane gets the LARGEST index whose plane lies at or below (true plane − pad), an upper one the SMALLEST at or above
+// (true plane + pad): the held box always contains the padded true one.  `pad` covers the rounding of the device's slab
+// test (rayz_device.hpp: bvh_box_hit), which therefore needs no slack of its own.
+struct PlaneGrid {
+    float glo[3] = {0, 0, 0}, cell[3] = {1, 1, 1};
+    double extent = 0; // largest span of the grid (part of the padding's scale)
+    // the grid over [lo - margin, hi + margin]: 65,535 cells per axis, the cell size rounded UP so that the last plane reaches
+    static PlaneGrid over(const double* lo, const double* hi, double margin) {
+        PlaneGrid g;
+        for (int k = 0; k < 3; ++k) {
+            const double a = lo[k] - margin, b = hi[k] + margin;
+            float f = (float)a;
+            if ((double)f > a) f = std::nextafter(f, -std::numeric_limits<float>::infinity());
+            g.glo[k] = f;
+            float c = (float)((b - (double)f) / 65535.0);
+            if (!(c > 0.0f)) c = std::numeric_limits<float>::min();
+            while ((double)f + 65535.0 * (double)c < b) c = std::nextafter(c, std::numeric_limits<float>::infinity());
+            g.cell[k] = c;
+            g.extent = std::fmax(g.extent, 65535.0 * (double)c);
+        }
+        return g;
+    }
+    double plane(int k, uint32_t i) const { return (double)glo[k] + (double)i * (double)cell[k]; }
+    uint32_t lower(int k, double v) const { // largest index with plane <= v (0 if even the first plane lies above: never, by `over`)
+        double x = std::floor((v - (double)glo[k]) / (double)cell[k]);
+        x = x < 0 ? 0 : (x > 65535.0 ? 65535.0 : x);
+        uint32_t i = (uint32_t)x;
+        while (i > 0 && plane(k, i) > v) --i;
+        while (i < 65535u && plane(k, i + 1) <= v) ++i;
+        return i;
+    }
+    uint32_t upper(int k, double v) const { // smallest index with plane >= v
+        double x = std::ceil((v - (double)glo[k]) / (double)cell[k]);
+        x = x < 0 ? 0 : (x > 65535.0 ? 65535.0 : x);
+        uint32_t i = (uint32_t)x;
+        while (i < 65535u && plane(k, i) < v) ++i;
+        while (i > 0 && plane(k, i - 1) >= v) --i;
+        return i;
+    }
+    // {lo.x | hi.x << 16, lo.y | hi.y << 16, lo.z | hi.z << 16} of a box padded by `pad` per side
+    void quantize(const Box& b, double pad, uint32_t out[3]) const {
+        for (int k = 0; k < 3; ++k) out[k] = lower(k, b.lo[k] - pad) | (upper(k, b.hi[k] + pad) << 16);
+    }
+};
+
 // Conservative narrowing of a box bound to R: never shrinks the box.
 template <class R> inline R roundDown(double v) {
     R r = (R)v;

@@ -75,11 +75,20 @@ template <class R> struct DevScene {
     const r4* tri;           // [3 * (nt_pad + kTriGroup)]
     uint32_t nt_pad, n_triangles;
     // BVH traversal (RAYZ_TRAVERSAL_BVH): the reference's tree in depth-first pre-order, DESIGN.md §6
-    const f4* bvh_nodes;     // [4 * n_inner] per INNER node, its two children's boxes IN F32 FOR BOTH PRECISIONS (the box
-                             // test only culls, §4.8) — one 64-B fetch, two slab tests:
-                             //   {L.lo, bits(L.id)}, {L.hi, bits(L.leaf)}, {R.lo, bits(R.id)}, {R.hi, bits(R.leaf)}
-                             //   id = the child's inner-node index << 6 (its record's byte offset); leaf = first << 4 | type1 << 3 | type0 << 2 | count
-                             //   (0 for an inner child)
+    const f4* bvh_nodes;     // per INNER node, its two children's boxes for BOTH precisions (the box test only culls, §4.8), in one
+                             // of two formats (bvh_quantized; the host picks by tree size, rayz_hip.hip: use_quantized_nodes):
+                             //  * f32 planes, 64 B = four 16-B loads:
+                             //      {L.lo.xyz, bits(L.ref)}, {L.hi.xyz, 0}, {R.lo.xyz, bits(R.ref)}, {R.hi.xyz, 0}
+                             //  * 16-bit plane indices on a scene-wide grid (plane = bvh_glo[k] + index · bvh_cell[k]; lower
+                             //    planes rounded down, upper ones up), 32 B = two loads:
+                             //      {L.lo.x | L.hi.x << 16, L.lo.y | L.hi.y << 16, L.lo.z | L.hi.z << 16, bits(L.ref)}, {R ...}
+                             //    Half the bytes: the walk is bound by the vector-memory address pipe, which works per
+                             //    instruction and per byte requested (profiles/r03/lds_top), and twice as many records fit
+                             //    the LDS top — at the price of 12 conversions per step: it pays for trees much larger than
+                             //    the LDS top (config 5: +7.7 %), not for those the top mostly covers (config 3: −2.7 %)
+                             //   ref = the child's record's byte offset (index << 6 or << 5), or
+                             //         kBvhLeafFlag | first << 4 | type1 << 3 | type0 << 2 | count
+    float bvh_glo[3], bvh_cell[3]; // the grid of the plane indices (f32 planes: glo = 0, cell = 1 — a plane IS its "index")
     const r4* bvh_leaf;      // [stride * slots] leaf order.  sphere: {c, r²}, {v, bits(hittable)};
                              //                  triangle: {v0, bits(hittable)}, {e1, 0}, {e2, 0}
     const d4* bvh_sph64;     // [2 * slots] leaf order, sphere slots only: {c, r²}, {v, 0}
@@ -1047,8 +1056,8 @@ template <> struct LeafBasis<double> {
 };
 template <class R> struct BvhQuery {
     // the slab test runs in f32 whatever R is: it only culls, and stays conservative under the conversion (§4.8)
-    V<float> inv;   // 1 / d per component (capped, bvh_begin)
-    V<float> noi;   // −o · inv per component: a slab distance is ONE fma, t = fm(plane, inv, noi)
+    V<float> qa;    // cell_k / d_k per component (1 / d_k capped, bvh_begin): a slab distance is ONE fma on the plane's
+    V<float> qb;    // 16-bit grid index i, t = fm(float(i), qa, qb), with qb = (glo_k − o_k) / d_k
     float tb32;     // tbest as the box steps see it: rounded UP to f32 (refreshed before every run of box steps)
     double inv_a2;  // 1 / (d·d) in f64 for the narrow phase
     R tbest;
@@ -1070,6 +1079,9 @@ template <class R> struct BvhQuery {
 // E = kBoxPadUlps·u·max(S, B) per side (u = 2^-24; S = bound on every ray origin, B = largest box coordinate) before
 // they are rounded outward to f32 — see bvh_box_hit for why that makes the test conservative.
 constexpr double kBoxPadUlps = 16.0;
+// a tree gets 32-byte records of 16-bit plane indices instead of 64-byte records of f32 planes when it has more than this
+// many times the inner nodes the LDS top would hold as f32 planes (DevScene::bvh_nodes; measured in profiles/r03/lds_top)
+constexpr size_t kQuantizeAboveTops = 8;
 __device__ __forceinline__ float round_up_f32(float v) { return v; }
 __device__ __forceinline__ float round_up_f32(double v) { return __double2float_ru(v); }
 __device__ __forceinline__ float round_down_f32(float v) { return v; }
@@ -1084,17 +1096,22 @@ constexpr float kInvCap = 0x1p64f;
 __device__ __forceinline__ float capped_inverse(float dk) { // (one v_med3_f32 behind the division)
     return __builtin_amdgcn_fmed3f(1.0f / dk, -kInvCap, kInvCap);
 }
-template <class R> __device__ __forceinline__ void bvh_begin(BvhQuery<R>& q, V<R> o, V<R> d, V<R> ud, uint32_t n_inner) {
+template <class R, class SC>
+__device__ __forceinline__ void bvh_begin(BvhQuery<R>& q, const SC& sc, V<R> o, V<R> d, V<R> ud, uint32_t n_inner) {
     q.lb.make(ud, o);
+    V<float> inv;
     if constexpr (sizeof(R) == 8) { // d_k narrowed to f32 first; a component beyond f32's range would make inv 0: held to ±2^100
-        q.inv = {capped_inverse(__builtin_amdgcn_fmed3f((float)d.x, -0x1p100f, 0x1p100f)),
-                 capped_inverse(__builtin_amdgcn_fmed3f((float)d.y, -0x1p100f, 0x1p100f)),
-                 capped_inverse(__builtin_amdgcn_fmed3f((float)d.z, -0x1p100f, 0x1p100f))};
+        inv = {capped_inverse(__builtin_amdgcn_fmed3f((float)d.x, -0x1p100f, 0x1p100f)),
+               capped_inverse(__builtin_amdgcn_fmed3f((float)d.y, -0x1p100f, 0x1p100f)),
+               capped_inverse(__builtin_amdgcn_fmed3f((float)d.z, -0x1p100f, 0x1p100f))};
     } else {
-        q.inv = {capped_inverse(d.x), capped_inverse(d.y), capped_inverse(d.z)};
+        inv = {capped_inverse(d.x), capped_inverse(d.y), capped_inverse(d.z)};
     }
-    // −o·inv with the origin at full precision, rounded once
-    q.noi = {(float)(-(o.x * (R)q.inv.x)), (float)(-(o.y * (R)q.inv.y)), (float)(-(o.z * (R)q.inv.z))};
+    // −o·inv with the origin at full precision, rounded once; then the grid folded in: a plane with index i lies at
+    // glo + i·cell, so its distance (glo + i·cell − o)·inv is fm(i, cell·inv, fm(glo, inv, −o·inv))
+    const V<float> noi{(float)(-(o.x * (R)inv.x)), (float)(-(o.y * (R)inv.y)), (float)(-(o.z * (R)inv.z))};
+    q.qa = {sc.bvh_cell[0] * inv.x, sc.bvh_cell[1] * inv.y, sc.bvh_cell[2] * inv.z};
+    q.qb = {fm(sc.bvh_glo[0], inv.x, noi.x), fm(sc.bvh_glo[1], inv.y, noi.y), fm(sc.bvh_glo[2], inv.z, noi.z)};
     const double ddx = d.x, ddy = d.y, ddz = d.z;
     q.inv_a2 = 1.0 / fm(ddz, ddz, fm(ddy, ddy, ddx * ddx));
     q.tbest = (R)__builtin_inff();
@@ -1105,24 +1122,44 @@ template <class R> __device__ __forceinline__ void bvh_begin(BvhQuery<R>& q, V<R
     q.top = kBvhDone; // = stack[0], the sentinel
 }
 
-// Slab test (AABB.hit, src/hit.zig:70-98) with 1/d and −o/d hoisted: each plane distance is one fma, and the test is
-// bare: t1 ≥ t0.  It is CONSERVATIVE — rounding never culls a box the f64 narrow phase would hit — because the BOX is
-// padded, not the comparison (round 3; rounds 1–2 paid a slack fma per box, a term Σ|noi| per segment and one more level
-// in the step's dependent chain).  With inv = (1/d)(1+e1), noi = −o·inv(1+e2) and the fma's own rounding e3, the distance
-// computed for a plane p is the EXACT distance of the true ray to a plane p' with
-//     p' − o = (1+e1)(1+e3)·[(p − o) − o·e2],     |p' − p| ≤ (|e1|+|e3|)|p − o| + |e2||o| (+ second order)
-// |e2|, |e3| ≤ u = 2^-24, |e1| ≤ u (R = float) or 2u (R = double: d_k narrowed to f32, then divided): |p' − p| ≤ 5.1u·(B + S)
-// for box coordinates |p| ≤ B and origins |o| ≤ S.  The host stores every box padded by E = 16u·max(S, B) ≥ that per side
-// (rayz_hip.hip: box_pad), so each computed slab interval contains the true box's exact one, for either sign of d_k.  A
-// direction component of 0 reaches here as ±1/K (bvh_begin): huge finite distances whose SIGN is right as long as the
-// origin is not within u·(|p − o| + |o|) < E of the plane — and a true ray that runs parallel to a slab is inside it only
-// if it is strictly between the TRUE planes, i.e. at least E inside the padded ones.
+// Slab test (AABB.hit, src/hit.zig:70-98) of one child box held as three words of 16-bit grid indices (lower | upper << 16
+// per axis): each plane distance is one conversion + one fma, t = fm(float(index), qa_k, qb_k), and the test is bare:
+// t1 ≥ t0.  It is CONSERVATIVE — rounding never culls a box the f64 narrow phase would hit — because the BOX carries the
+// slack, not the comparison.  With inv = (1/d)(1+e1), noi = −o·inv(1+e2), qa = cell·inv(1+e4), qb = (glo·inv + noi)(1+e5)
+// and the fma's own rounding e3, the distance computed for index i is the EXACT distance of the true ray to a plane p' with
+//     p' − o = (1+e1)(1+e3)·[i·cell(1+e4) + (glo − o − o·e2)(1+e5)]
+//     |p' − p| ≤ (|e1|+|e3|)|p − o| + |e4|·i·cell + |e5||glo − o| + |e2||o|   (+ second order),   p = glo + i·cell
+// every |e| ≤ u = 2^-24 except |e1| ≤ 2u for R = double (d_k narrowed to f32, then divided): |p' − p| ≤ 4u(B + S) + u·X + u(B + S)
+// + u·S < 7u·(max(S, B) + X) for box coordinates |p|, |glo| ≤ B, origins |o| ≤ S and a grid of extent X.  The host picks
+// each lower index as the LARGEST whose plane lies at or below the true plane − E, each upper one as the SMALLEST at or above
+// the true plane + E, E = 16u·(max(S, B) + X) (rayz_hip.hip: quantize_box), so each computed slab interval contains the true
+// box's exact one, for either sign of d_k.  A direction component of 0 reaches here as ±1/K (bvh_begin): huge finite
+// distances whose SIGN is right as long as the origin is not within rounding (< E) of the plane — and a true ray that
+// runs parallel to a slab is inside it only if it is strictly between the TRUE planes, i.e. at least E inside the held ones.
 // `tmin` is the caller's tmin rounded DOWN to f32, q.tb32 tbest rounded UP.  Returns the entry distance through `t0`.
+template <class R, bool kUniformTmin>
+__device__ __forceinline__ bool bvh_box_hit_planes(V<float> lo, V<float> hi, const BvhQuery<R>& q, float tmin, float& t0);
+__device__ __forceinline__ float plane_lo(uint32_t w) { // float(w & 0xffff): one v_cvt_f32_u32 with a 16-bit source select
+    float r;
+    asm("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(r) : "v"(w));
+    return r;
+}
+__device__ __forceinline__ float plane_hi(uint32_t w) { // float(w >> 16)
+    float r;
+    asm("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(r) : "v"(w));
+    return r;
+}
 template <class R, bool kUniformTmin = false>
-__device__ __forceinline__ bool bvh_box_hit(f4 lo, f4 hi, const BvhQuery<R>& q, float tmin, float& t0) {
-    const float ax = fm(lo.x, q.inv.x, q.noi.x), bx = fm(hi.x, q.inv.x, q.noi.x);
-    const float ay = fm(lo.y, q.inv.y, q.noi.y), by = fm(hi.y, q.inv.y, q.noi.y);
-    const float az = fm(lo.z, q.inv.z, q.noi.z), bz = fm(hi.z, q.inv.z, q.noi.z);
+__device__ __forceinline__ bool bvh_box_hit(uint32_t wx, uint32_t wy, uint32_t wz, const BvhQuery<R>& q, float tmin, float& t0) {
+    return bvh_box_hit_planes<R, kUniformTmin>(V<float>{plane_lo(wx), plane_lo(wy), plane_lo(wz)},
+                                               V<float>{plane_hi(wx), plane_hi(wy), plane_hi(wz)}, q, tmin, t0);
+}
+// .. of a box held as f32 planes (glo = 0, cell = 1: qa = 1/d, qb = −o/d, and a plane is its own "index")
+template <class R, bool kUniformTmin>
+__device__ __forceinline__ bool bvh_box_hit_planes(V<float> lo, V<float> hi, const BvhQuery<R>& q, float tmin, float& t0) {
+    const float ax = fm(lo.x, q.qa.x, q.qb.x), bx = fm(hi.x, q.qa.x, q.qb.x);
+    const float ay = fm(lo.y, q.qa.y, q.qb.y), by = fm(hi.y, q.qa.y, q.qb.y);
+    const float az = fm(lo.z, q.qa.z, q.qb.z), bz = fm(hi.z, q.qa.z, q.qb.z);
     // (tmin and tbest are never NaN: max_bound / min_bound spare the canonicalising copy fmax / fmin would put in front of
     // every use — two vector instructions per step)
     // (kUniformTmin: the trace kernels' tmin is the launch's, the same for every lane; the known-answer kernel's is per record)
@@ -1133,34 +1170,64 @@ __device__ __forceinline__ bool bvh_box_hit(f4 lo, f4 hi, const BvhQuery<R>& q, 
     return t1 >= t0;
 }
 
+// The node array's base as scalar registers of its own (the step's global loads take it as their SGPR base: read straight
+// out of the kernel-argument block under scalar-register pressure, hipcc hands the inline assembly a VGPR pair).
+__device__ __forceinline__ const f4* scalar_base(const f4* p) {
+    const unsigned long long nb = (unsigned long long)(uintptr_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)nb), hi = __builtin_amdgcn_readfirstlane((uint32_t)(nb >> 32));
+    return (const f4*)(uintptr_t)((unsigned long long)lo | ((unsigned long long)hi << 32));
+}
 // Phase N — one step of a lane that holds an inner node: fetch the node's record, slab-test both children, push the
 // farther hit child (inner index or flagged leaf descriptor alike) and take the nearer one; with nothing hit, take the
 // top of the stack instead.  Whatever the lane then holds says what it does next: an inner node → another step, a leaf →
 // parked for phase L, kBvhDone (the sentinel under the stack) → walk complete.  Branch-free: the push lands above the
 // top when there is nothing to push, the pop is a read every stepping lane makes.  `stack` is this lane's column of
 // the workgroup's LDS stack (entry s at stack[s * 256]).
-template <class R, uint32_t WG>
+template <class R, uint32_t WG, bool QUANT>
 __device__ __forceinline__ void bvh_node_step(const DevScene<R>& sc, const f4* nodes_base, BvhQuery<R>& q, float tmin, uint32_t* stack
 #ifdef RAYZ_BVH_PROFILE
                                               , unsigned long long& g_fetch_ticks
 #endif
 ) {
-    f4 llo, lhi, rlo, rhi;
 #ifdef RAYZ_BVH_PROFILE
     const unsigned long long tl0 = __builtin_amdgcn_s_memtime();
 #endif
-    {
-        // Both homes of a node — the LDS copy of the tree's top (at LDS address 0), global memory for the rest — are read
-        // from the SAME 32-bit offset (index << 6): the lanes of either kind take turns under exec, into the same
-        // registers.  Two vector instructions (a compare, a shift) instead of the nine a flat-address select costs.
-        // (an inner reference IS the record's byte offset, index << 6: the host keeps the node count below 2^25; sc.bvh_top
-        //  is a byte count likewise — no shift, no second register)
-        const unsigned long long in_top = __ballot(q.cur < sc.bvh_top);
-        const uint32_t off = q.cur;
-        unsigned long long saved;
+    // Both homes of a node — the LDS copy of the tree's top (at LDS address 0), global memory for the rest — are read
+    // from the SAME 32-bit offset (the reference itself): the lanes of either kind take turns under exec, into the same
+    // registers.  Two vector instructions (a compare, a shift) instead of the nine a flat-address select costs.
+    // (an inner reference IS its record's byte offset, index << 6 or << 5: the host keeps the node count below 2^25;
+    //  sc.bvh_top is a byte count likewise — no shift, no second register)
+    const unsigned long long in_top = __ballot(q.cur < sc.bvh_top);
+    const uint32_t off = q.cur;
+    unsigned long long saved;
+    float tl, tr;
+    bool hl, hr;
+    uint32_t l, r; // each child's reference: an inner record's offset, or kBvhLeafFlag | leaf descriptor
+    if constexpr (QUANT) {
+        u4 nl, nr; // the two children: {x, y, z plane words, reference}
         asm volatile("s_mov_b64 %[sv], exec\n\t"
                      "s_and_b64 exec, %[sv], %[mt]\n\t" // (SCC = some lane: an empty turn is skipped — the memory
                      "s_cbranch_scc0 1f\n\t"            //  pipes would still spend their cycles on it)
+                     "ds_read_b128 %[n0], %[off]\n\t"
+                     "ds_read_b128 %[n1], %[off] offset:16\n"
+                     "1:\n\t"
+                     "s_andn2_b64 exec, %[sv], %[mt]\n\t"
+                     "s_cbranch_scc0 2f\n\t"
+                     "global_load_dwordx4 %[n0], %[off], %[base]\n\t"
+                     "global_load_dwordx4 %[n1], %[off], %[base] offset:16\n"
+                     "2:\n\t"
+                     "s_mov_b64 exec, %[sv]\n\t"
+                     "s_waitcnt vmcnt(0) lgkmcnt(0)"
+                     : [n0] "=&v"(nl), [n1] "=&v"(nr), [sv] "=&s"(saved)
+                     : [off] "v"(off), [mt] "s"(in_top), [base] "s"(nodes_base)
+                     : "memory", "scc");
+        hl = bvh_box_hit<R, true>(nl.x, nl.y, nl.z, q, tmin, tl), hr = bvh_box_hit<R, true>(nr.x, nr.y, nr.z, q, tmin, tr);
+        l = nl.w, r = nr.w;
+    } else {
+        f4 llo, lhi, rlo, rhi;
+        asm volatile("s_mov_b64 %[sv], exec\n\t"
+                     "s_and_b64 exec, %[sv], %[mt]\n\t"
+                     "s_cbranch_scc0 1f\n\t"
                      "ds_read_b128 %[n0], %[off]\n\t"
                      "ds_read_b128 %[n1], %[off] offset:16\n\t"
                      "ds_read_b128 %[n2], %[off] offset:32\n\t"
@@ -1178,19 +1245,18 @@ __device__ __forceinline__ void bvh_node_step(const DevScene<R>& sc, const f4* n
                      : [n0] "=&v"(llo), [n1] "=&v"(lhi), [n2] "=&v"(rlo), [n3] "=&v"(rhi), [sv] "=&s"(saved)
                      : [off] "v"(off), [mt] "s"(in_top), [base] "s"(nodes_base)
                      : "memory", "scc");
+        hl = bvh_box_hit_planes<R, true>(V<float>{llo.x, llo.y, llo.z}, V<float>{lhi.x, lhi.y, lhi.z}, q, tmin, tl);
+        hr = bvh_box_hit_planes<R, true>(V<float>{rlo.x, rlo.y, rlo.z}, V<float>{rhi.x, rhi.y, rhi.z}, q, tmin, tr);
+        l = bits(llo.w), r = bits(rlo.w);
     }
 #ifdef RAYZ_BVH_PROFILE // time from issuing the node fetch to having it (the wave's own view), accumulated in g_prof_fetch
     g_fetch_ticks += __builtin_amdgcn_s_memtime() - tl0;
 #endif
-    float tl, tr;
-    const bool hl = bvh_box_hit<R, true>(llo, lhi, q, tmin, tl), hr = bvh_box_hit<R, true>(rlo, rhi, q, tmin, tr);
     // Which child was hit decides everything below, so the decisions live as WAVE MASKS in scalar registers (the boolean
     // algebra runs on the scalar unit, which has slack; the vector unit, which has none, spends one v_cndmask per choice):
     const unsigned long long ml = __ballot(hl), mr = __ballot(hr), mlt = __ballot(tr < tl);
     const unsigned long long swap = mr & (~ml | mlt), both = ml & mr, none = ~(ml | mr);
-    // each child's reference rides in its lo.w: an inner index, or kBvhLeafFlag | leaf descriptor.  Nearer child first
-    // (a child that was not hit may ride along as `near` or `far`: `none` and `both` decide what is used)
-    const uint32_t l = bits(llo.w), r = bits(rlo.w);
+    // Nearer child first (a child that was not hit may ride along as `near` or `far`: `none` and `both` decide what is used)
     const uint32_t near = mask_select(swap, r, l), far = mask_select(swap, l, r);
     stack[WG * (q.sp + 1u)] = far; // lands above the top unless both were hit
     const uint32_t sp = mask_add(q.sp, both);
@@ -1287,7 +1353,7 @@ constexpr int kBvhKeepStepping = 16; // phase N continues while at least this ma
 #define RAYZ_BVH_WAVES_F64 4 // 151 and ran 3 waves per SIMD before: +13 % from the fourth)
 #endif
 template <class R> constexpr int bvh_waves() { return sizeof(R) == 8 ? RAYZ_BVH_WAVES_F64 : RAYZ_BVH_WAVES; }
-template <class R> __global__ __launch_bounds__(RAYZ_BVH_WG, (bvh_waves<R>() * 256 >= RAYZ_BVH_WG ? bvh_waves<R>() * 256 / RAYZ_BVH_WG : 1))
+template <class R, bool QUANT> __global__ __launch_bounds__(RAYZ_BVH_WG, (bvh_waves<R>() * 256 >= RAYZ_BVH_WG ? bvh_waves<R>() * 256 / RAYZ_BVH_WG : 1))
 void trace_kernel_bvh(const TraceArgs<R> A) {
     typedef typename VecOf<R>::type r4;
     const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -1297,8 +1363,8 @@ void trace_kernel_bvh(const TraceArgs<R> A) {
     Pcg32 g{0, 1};
     V<R> o{0, 0, 0}, d{0, 0, 1}, ud{0, 0, 1}, thr{1, 1, 1}, acc{0, 0, 0};
     BvhQuery<R> q;
-    q.inv = {1.0f, 1.0f, 1.0f};
-    q.noi = {0.0f, 0.0f, 0.0f};
+    q.qa = {1.0f, 1.0f, 1.0f};
+    q.qb = {0.0f, 0.0f, 0.0f};
     q.tb32 = 0.0f;
     q.inv_a2 = 1.0;
     q.tbest = R(0);
@@ -1320,6 +1386,7 @@ void trace_kernel_bvh(const TraceArgs<R> A) {
     f4* top = (f4*)lds_words;
     uint32_t* stack = lds_words + A.bvh_top_words + kBvhWg + threadIdx.x; // (one guard row under entry 0: BvhQuery::top)
     for (uint32_t k = threadIdx.x; k < A.sc.bvh_top / 16u; k += kBvhWg) top[k] = A.sc.bvh_nodes[k];
+    const f4* nodes_base = scalar_base(A.sc.bvh_nodes);
     stack[0] = kBvhDone; // the sentinel under every lane's stack
     __syncthreads();
     R time = 0;
@@ -1380,7 +1447,7 @@ void trace_kernel_bvh(const TraceArgs<R> A) {
         //      for the per-segment set-up (unit direction, slab constants) ----
         if (fresh) {
             ud = unit(d);
-            bvh_begin<R>(q, o, d, ud, n_nodes);
+            bvh_begin<R>(q, A.sc, o, d, ud, n_nodes);
         }
         // .. then the oversized hittables kept out of the tree: the walk starts with their tbest and culls behind it
         if (A.sc.bvh_n_big_leaves != 0u && __ballot(fresh) != 0ull) {
@@ -1413,16 +1480,16 @@ void trace_kernel_bvh(const TraceArgs<R> A) {
                 px3[0] += __popcll(__ballot((int32_t)q.cur < 0));
                 px3[1] += __popcll(__ballot(alive && q.cur == kBvhDone));
                 px3[2] += __popcll(__ballot(!alive));
-                if (can_step) bvh_node_step<R, kBvhWg>(A.sc, A.sc.bvh_nodes, q, tmin32, stack, fetch_ticks);
+                if (can_step) bvh_node_step<R, kBvhWg, QUANT>(A.sc, nodes_base, q, tmin32, stack, fetch_ticks);
 #else
-                if (can_step) bvh_node_step<R, kBvhWg>(A.sc, A.sc.bvh_nodes, q, tmin32, stack);
+                if (can_step) bvh_node_step<R, kBvhWg, QUANT>(A.sc, nodes_base, q, tmin32, stack);
                 // .. and a second step for the lanes that still hold an inner node, without a new wave-level decision (lane
                 // counts against thresholds are scalar work with a taken branch at its end: every other step is enough —
                 // +1 % on configs 3 / 5, +2.6 % on config 2, profiles/r03/bvh_step/unroll.log; three or four lose it again)
                 {
                     const bool again = q.cur < kBvhDone;
                     node_tests += 2u * (uint32_t)__popcll(__ballot(again));
-                    if (again) bvh_node_step<R, kBvhWg>(A.sc, A.sc.bvh_nodes, q, tmin32, stack);
+                    if (again) bvh_node_step<R, kBvhWg, QUANT>(A.sc, nodes_base, q, tmin32, stack);
                 }
 #endif
                 node_tests += 2u * (uint32_t)n_can;
@@ -1547,7 +1614,7 @@ constexpr int kBvh2Swap = 6;     // run the swap when this many lanes have an id
 #ifndef RAYZ_BVH2_WAVES
 #define RAYZ_BVH2_WAVES 3 // both contexts live in registers: 168 VGPRs
 #endif
-template <class R> __global__ __launch_bounds__(256, RAYZ_BVH2_WAVES) void trace_kernel_bvh2(const TraceArgs<R> A) {
+template <class R, bool QUANT> __global__ __launch_bounds__(256, RAYZ_BVH2_WAVES) void trace_kernel_bvh2(const TraceArgs<R> A) {
     typedef typename VecOf<R>::type r4;
     const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     const uint32_t n_nodes = A.sc.bvh_n_nodes;
@@ -1565,14 +1632,7 @@ template <class R> __global__ __launch_bounds__(256, RAYZ_BVH2_WAVES) void trace
     stack[0] = kBvhDone;
     __syncthreads();
 
-    // the node array's base as scalar registers of its own (the step's global loads take it as their SGPR base: under this
-    // kernel's scalar-register pressure hipcc otherwise hands the inline assembly a VGPR pair)
-    const f4* nodes_base;
-    {
-        const unsigned long long nb = (unsigned long long)(uintptr_t)A.sc.bvh_nodes;
-        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)nb), hi = __builtin_amdgcn_readfirstlane((uint32_t)(nb >> 32));
-        nodes_base = (const f4*)(uintptr_t)((unsigned long long)lo | ((unsigned long long)hi << 32));
-    }
+    const f4* nodes_base = scalar_base(A.sc.bvh_nodes);
     PathCtx<R> c0, c1; // the lane's two path contexts; the walker's is c[wsel], the parked one c[wsel ^ 1]
     ctx_init<R>(c0);
     ctx_init<R>(c1);
@@ -1580,8 +1640,8 @@ template <class R> __global__ __launch_bounds__(256, RAYZ_BVH2_WAVES) void trace
     V<R> o{0, 0, 0}, d{0, 0, 1}, ud{0, 0, 1};
     R time = 0;
     BvhQuery<R> q;
-    q.inv = {1.0f, 1.0f, 1.0f};
-    q.noi = {0.0f, 0.0f, 0.0f};
+    q.qa = {1.0f, 1.0f, 1.0f};
+    q.qb = {0.0f, 0.0f, 0.0f};
     q.tb32 = 0.0f;
     q.inv_a2 = 1.0;
     q.tbest = R(0);
@@ -1667,7 +1727,7 @@ template <class R> __global__ __launch_bounds__(256, RAYZ_BVH2_WAVES) void trace
             // out of the tree: the walk starts with their tbest
             if (fresh) {
                 pud = unit(pd);
-                bvh_begin<R>(pq, po, pd, pud, n_nodes);
+                bvh_begin<R>(pq, A.sc, po, pd, pud, n_nodes);
             }
             if (A.sc.bvh_n_big_leaves != 0u && __ballot(fresh) != 0ull) {
                 if (fresh) {
@@ -1737,9 +1797,9 @@ template <class R> __global__ __launch_bounds__(256, RAYZ_BVH2_WAVES) void trace
                 px3[0] += __popcll(__ballot((int32_t)q.cur < 0));
                 px3[1] += __popcll(__ballot(q.cur == kBvhDone));
                 unsigned long long ft_ = 0;
-                if (can_step) bvh_node_step<R, kBvh2Wg>(A.sc, nodes_base, q, tmin32, stack, ft_);
+                if (can_step) bvh_node_step<R, kBvh2Wg, QUANT>(A.sc, nodes_base, q, tmin32, stack, ft_);
 #else
-                if (can_step) bvh_node_step<R, kBvh2Wg>(A.sc, nodes_base, q, tmin32, stack);
+                if (can_step) bvh_node_step<R, kBvh2Wg, QUANT>(A.sc, nodes_base, q, tmin32, stack);
 #endif
                 node_tests += 2u * (uint32_t)n_can;
             }
@@ -1867,17 +1927,26 @@ template <class R> __global__ __launch_bounds__(64) void kat_kernel(uint32_t op,
         r[7] = (double)g.i;
         break;
     }
-    case 3: { // BOX_HIT: lo(3) hi(3) o(3) d(3) tmin tmax -> hit, t_entry
+    case 3: { // BOX_HIT: lo(3) hi(3) o(3) d(3) tmin tmax ... format[26] -> hit, t_entry.  The box as the device holds it, in
+              // either record format (DevScene::bvh_nodes), made by the host from the record as the scene upload makes it
+              // (rayz_hip_kat): format 0: a[14..19] = 16-bit plane indices lo.xyz hi.xyz, a[20..25] = grid origin and cell size;
+              // format 1: a[14..19] = the padded planes rounded outward to f32, the grid = origin 0, cell 1
+        DevScene<R> g{};
+        for (int k = 0; k < 3; ++k) g.bvh_glo[k] = (float)a[20 + k], g.bvh_cell[k] = (float)a[23 + k];
         BvhQuery<R> q;
-        bvh_begin<R>(q, v3(6), v3(9), unit(v3(9)), 1u);
+        const V<R> d = v3(9);
+        bvh_begin<R>(q, g, v3(6), d, unit(d), 1u);
         q.tbest = (R)a[13];
         q.tb32 = round_up_f32(q.tbest);
         float t0;
-        // the box as the device holds it: f32, rounded outward (host: bvh_build.hpp roundDown / roundUp)
-        // (.. padded by a[14] = E, which the host computes from the record as the scene upload would: rayz_hip_kat)
-        const f4 lo = {__double2float_rd(a[0] - a[14]), __double2float_rd(a[1] - a[14]), __double2float_rd(a[2] - a[14]), 0.0f};
-        const f4 hi = {__double2float_ru(a[3] + a[14]), __double2float_ru(a[4] + a[14]), __double2float_ru(a[5] + a[14]), 0.0f};
-        r[0] = bvh_box_hit<R>(lo, hi, q, round_down_f32((R)a[12]), t0) ? 1.0 : 0.0;
+        if (a[26] != 0.0) {
+            r[0] = bvh_box_hit_planes<R, false>(V<float>{(float)a[14], (float)a[15], (float)a[16]}, V<float>{(float)a[17], (float)a[18], (float)a[19]},
+                                                q, round_down_f32((R)a[12]), t0) ? 1.0 : 0.0;
+        } else {
+            const uint32_t wx = (uint32_t)a[14] | ((uint32_t)a[17] << 16), wy = (uint32_t)a[15] | ((uint32_t)a[18] << 16),
+                           wz = (uint32_t)a[16] | ((uint32_t)a[19] << 16);
+            r[0] = bvh_box_hit<R>(wx, wy, wz, q, round_down_f32((R)a[12]), t0) ? 1.0 : 0.0;
+        }
         r[1] = (double)t0;
         break;
     }

@@ -111,11 +111,13 @@ template <class R> struct SceneBuffers {
     r4* mat = nullptr;
     r4* tex = nullptr;
     r4* tri = nullptr;
-    f4* bvh_nodes = nullptr; // BVH traversal only (f32 boxes for both precisions: the box test only culls)
+    u4* bvh_nodes = nullptr; // BVH traversal only (f32 planes or 16-bit plane indices, for both precisions: the box test only culls)
+    bool quantized = false;  // .. which: DevScene::bvh_nodes
     r4* bvh_leaf = nullptr;
     uint32_t nt_pad = 0, bvh_leaf_stride = 2, bvh_n_inner = 0;
     uint32_t n_big_leaves = 0, big_desc[4] = {0, 0, 0, 0};
     uint32_t bvh_top = 0; // inner-node records the BVH kernel copies to LDS
+    rayz_bvh::PlaneGrid grid; // the grid the node records' 16-bit plane indices live on (f32 planes: origin 0, cell 1)
     double pad_S = 0; // the origin bound S the filter radii of these buffers were padded for
     bool ready = false, bvh_ready = false;
     void release() {
@@ -455,7 +457,7 @@ template <class R> int upload_bvh_body(RayzScene* s, SceneBuffers<R>& b) {
     // one record per INNER node holding its two children's boxes (narrowed outward to f32: never smaller than the f64
     // box) + in lo.w where each child leads: an inner index, or kBvhLeafFlag | leaf descriptor
     // (first << 4 | type1 << 3 | type0 << 2 | count)
-    std::vector<f4> nodes;
+    std::vector<u4> nodes;
     std::vector<r4> leaf;
     // the inner nodes the kernel keeps in LDS (the tree's "top") are numbered first, the rest in pre-order
     std::vector<uint32_t> inner_index(t.nodes.size(), 0xffffffffu), inner_order;
@@ -464,7 +466,15 @@ template <class R> int upload_bvh_body(RayzScene* s, SceneBuffers<R>& b) {
         // top-of-tree records kept in LDS: as many as fit beside the stacks of the one-path kernel's workgroup (the two-path
         // kernel, with its smaller workgroups, keeps a prefix of them); RAYZ_DEBUG_BVH_TOP lowers the cap
         const size_t stacks = ((size_t)t.depth + 3) * kBvhWg * sizeof(uint32_t);
-        const uint32_t fit = stacks < kBvhLdsBudget ? (uint32_t)((kBvhLdsBudget - stacks) / 64) : 0u;
+        const size_t lds_for_top = stacks < kBvhLdsBudget ? kBvhLdsBudget - stacks : 0;
+        // WHICH record format (DevScene::bvh_nodes): 16-bit plane indices halve the bytes a step fetches and double the
+        // records the LDS top holds, for 12 conversions per step — worth it only when most steps fetch from global memory,
+        // i.e. for a tree much larger than the f32 top (measured: profiles/r03/lds_top).  RAYZ_DEBUG_BVH_NODES forces one.
+        size_t inner_total = 0;
+        for (const rayz_bvh::FlatNode& n : t.nodes) inner_total += n.count == 0;
+        const long long format = tuning(RAYZ_DEBUG_BVH_NODES, 0);
+        b.quantized = format == 2 || (format == 0 && inner_total > kQuantizeAboveTops * (lds_for_top / 64));
+        const uint32_t fit = (uint32_t)(lds_for_top / (b.quantized ? 32 : 64));
         const uint32_t top_cap = (uint32_t)std::min<long long>(tuning(RAYZ_DEBUG_BVH_TOP, fit), fit);
         // WHICH records: grown from the root, always taking the candidate whose box has the largest surface area next — the
         // chance that a ray visits a node goes with its box's area, and never exceeds its parent's (RAYZ_DEBUG_BVH_TOP_ORDER
@@ -494,25 +504,48 @@ template <class R> int upload_bvh_body(RayzScene* s, SceneBuffers<R>& b) {
                 inner_order.push_back((uint32_t)i);
             }
     }
-    // the boxes go to the device padded: the slab test carries no slack of its own (rayz_device.hpp: bvh_box_hit)
+    // the boxes go to the device PADDED: the slab test carries no slack of its own (rayz_device.hpp: bvh_box_hit;
+    // E = 16u·max(S, B) for f32 planes rounded outward, 16u·(max(S, B) + X) for plane indices on a grid of extent X)
     double box_B = 0;
-    for (const rayz_bvh::FlatNode& n : t.nodes)
+    rayz_bvh::Box all;
+    for (const rayz_bvh::FlatNode& n : t.nodes) {
+        all.enclose(n.box);
         for (int k = 0; k < 3; ++k) box_B = std::max({box_B, std::fabs(n.box.lo[k]), std::fabs(n.box.hi[k])});
-    const double box_pad = kBoxPadUlps * unit_roundoff<float>() * std::max(b.pad_S, box_B);
+    }
+    if (t.nodes.empty())
+        for (int k = 0; k < 3; ++k) all.lo[k] = all.hi[k] = 0;
+    double box_pad = kBoxPadUlps * unit_roundoff<float>() * std::max(b.pad_S, box_B);
+    b.grid = rayz_bvh::PlaneGrid{}; // origin 0, cell 1: a plane is its own index
+    if (b.quantized) {
+        box_pad = kBoxPadUlps * unit_roundoff<float>() * (std::max(b.pad_S, box_B) + 2.0 * box_B);
+        b.grid = rayz_bvh::PlaneGrid::over(all.lo, all.hi, 2.0 * box_pad);
+        box_pad = kBoxPadUlps * unit_roundoff<float>() * (std::max(b.pad_S, box_B) + b.grid.extent); // (extent <= 2 B + 4 pad: within the margin)
+    }
     auto leaf_info = [&](const rayz_bvh::FlatNode& n) {
         uint32_t info = (n.first << 4) | n.count;
         for (uint32_t k = 0; k < n.count; ++k)
             if (t.order[n.first + k] >= ns) info |= 1u << (2 + k);
         return info;
     };
+    auto fbits = [](float f) {
+        uint32_t w;
+        std::memcpy(&w, &f, 4);
+        return w;
+    };
     auto child = [&](size_t c) {
         const rayz_bvh::FlatNode& n = t.nodes[c];
         const bool is_leaf = n.count != 0;
-        nodes.push_back(f4{rayz_bvh::roundDown<float>(n.box.lo[0] - box_pad), rayz_bvh::roundDown<float>(n.box.lo[1] - box_pad),
-                           rayz_bvh::roundDown<float>(n.box.lo[2] - box_pad),
-                           Bits<float>::from(is_leaf ? (kBvhLeafFlag | leaf_info(n)) : (inner_index[c] << 6))}); // inner: byte offset
-        nodes.push_back(f4{rayz_bvh::roundUp<float>(n.box.hi[0] + box_pad), rayz_bvh::roundUp<float>(n.box.hi[1] + box_pad),
-                           rayz_bvh::roundUp<float>(n.box.hi[2] + box_pad), 0.0f});
+        const uint32_t ref = is_leaf ? (kBvhLeafFlag | leaf_info(n)) : (inner_index[c] << (b.quantized ? 5 : 6)); // inner: byte offset
+        if (b.quantized) {
+            uint32_t w[3];
+            b.grid.quantize(n.box, box_pad, w);
+            nodes.push_back(u4{w[0], w[1], w[2], ref});
+        } else {
+            nodes.push_back(u4{fbits(rayz_bvh::roundDown<float>(n.box.lo[0] - box_pad)), fbits(rayz_bvh::roundDown<float>(n.box.lo[1] - box_pad)),
+                               fbits(rayz_bvh::roundDown<float>(n.box.lo[2] - box_pad)), ref});
+            nodes.push_back(u4{fbits(rayz_bvh::roundUp<float>(n.box.hi[0] + box_pad)), fbits(rayz_bvh::roundUp<float>(n.box.hi[1] + box_pad)),
+                               fbits(rayz_bvh::roundUp<float>(n.box.hi[2] + box_pad)), 0u});
+        }
     };
     if (!t.nodes.empty() && t.nodes[0].count != 0) { // the whole pool fits one leaf: a root record whose two child
         child(0);                                     // slots both name it (the repeat cannot change the result)
@@ -786,7 +819,8 @@ int render_impl(RayzScene* s, const DeviceCtx& ctx, SceneBuffers<R>& b, const Ra
     A.sc.tri = b.tri;
     A.sc.nt_pad = b.nt_pad;
     A.sc.n_triangles = (uint32_t)s->triangles.size();
-    A.sc.bvh_nodes = b.bvh_nodes;
+    A.sc.bvh_nodes = (const f4*)b.bvh_nodes;
+    for (int k = 0; k < 3; ++k) A.sc.bvh_glo[k] = b.grid.glo[k], A.sc.bvh_cell[k] = b.grid.cell[k];
     A.sc.bvh_leaf = b.bvh_leaf;
     A.sc.bvh_sph64 = s->narrow.bvh_sph64;
     A.sc.bvh_n_nodes = use_bvh ? b.bvh_n_inner : 0u;
@@ -829,19 +863,22 @@ int render_impl(RayzScene* s, const DeviceCtx& ctx, SceneBuffers<R>& b, const Ra
     // the tree's top: first in LDS.  The scene numbered b.bvh_top records breadth-first for the one-path kernel's workgroup;
     // a kernel whose workgroup has less LDS to spare (two paths per lane: three 256-thread workgroups per CU) keeps a prefix
     uint32_t top_records = use_bvh ? b.bvh_top : 0u;
-    if (two_paths) top_records = std::min<uint32_t>(top_records, 256u);
-    const size_t bvh_top_bytes = (size_t)top_records * 4 * sizeof(f4);
+    if (two_paths) top_records = std::min<uint32_t>(top_records, b.quantized ? 512u : 256u);
+    const size_t bvh_top_bytes = (size_t)top_records * (b.quantized ? 32 : 64);
     // (+ RAYZ_DEBUG_LDS_PAD unused bytes: an occupancy experiment — fewer workgroups per CU, the same code)
     const size_t bvh_lds = bvh_top_bytes + bvh_stack_bytes + (use_bvh ? (size_t)tuning(RAYZ_DEBUG_LDS_PAD, 0) : 0);
     A.bvh_top_words = (uint32_t)(bvh_top_bytes / sizeof(uint32_t));
     A.sc.bvh_top = (uint32_t)bvh_top_bytes; // the walk compares byte offsets
-    if (use_bvh && bvh_lds > 64 * 1024) { // a workgroup that asks for more than 64 KB of LDS has to say so first
-        if (two_paths) HIP_TRY(hipFuncSetAttribute((const void*)trace_kernel_bvh2<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bvh_lds));
-        else HIP_TRY(hipFuncSetAttribute((const void*)trace_kernel_bvh<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bvh_lds));
+    typedef void (*Kernel)(const TraceArgs<R>);
+    Kernel kernel = trace_kernel<R, 1>;
+    if (two_paths) {
+        if constexpr (sizeof(R) == 4) kernel = b.quantized ? trace_kernel_bvh2<float, true> : trace_kernel_bvh2<float, false>;
+    } else if (use_bvh) {
+        kernel = b.quantized ? trace_kernel_bvh<R, true> : trace_kernel_bvh<R, false>;
     }
-    if (two_paths) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, trace_kernel_bvh2<float>, block, bvh_lds));
-    else if (use_bvh) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, trace_kernel_bvh<R>, block, bvh_lds));
-    else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, trace_kernel<R, 1>, block, 0));
+    if (use_bvh && bvh_lds > 64 * 1024) // a workgroup that asks for more than 64 KB of LDS has to say so first
+        HIP_TRY(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bvh_lds));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kernel, block, use_bvh ? bvh_lds : 0));
     if (blocks_per_cu < 1) blocks_per_cu = 1;
     uint64_t grid = (uint64_t)ctx.num_cu * blocks_per_cu;
     // (a lane of the two-path kernel holds two items)
@@ -851,13 +888,7 @@ int render_impl(RayzScene* s, const DeviceCtx& ctx, SceneBuffers<R>& b, const Ra
     s->last_two_paths = two_paths;
     HIP_TRY(hipMemsetAsync(s->counters, 0, 32 * sizeof(unsigned long long), stream));
     HIP_TRY(hipEventRecord(s->ev0, stream));
-    if (two_paths) {
-        if constexpr (sizeof(R) == 4) hipLaunchKernelGGL(trace_kernel_bvh2<float>, dim3((uint32_t)grid), dim3(block), bvh_lds, stream, A);
-    } else if (use_bvh) {
-        hipLaunchKernelGGL(trace_kernel_bvh<R>, dim3((uint32_t)grid), dim3(block), bvh_lds, stream, A);
-    } else {
-        hipLaunchKernelGGL((trace_kernel<R, 1>), dim3((uint32_t)grid), dim3(block), 0, stream, A);
-    }
+    hipLaunchKernelGGL(kernel, dim3((uint32_t)grid), dim3(block), use_bvh ? bvh_lds : 0, stream, A);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev1, stream));
     hipLaunchKernelGGL(resolve_kernel<R>, dim3((A.shard_pixels + 255) / 256), dim3(256), 0, stream,
@@ -1475,10 +1506,24 @@ int rayz_hip_kat(uint32_t op, uint32_t precision, const double* in, uint32_t n, 
                 if (!(nu >= 0 && nu <= RAYZ_KAT_IN_STRIDE - (at + 1) && nu == std::floor(nu)))
                     return fail(RAYZ_ERR_BAD_ARG, "record %u: n_u = %g is not an integer in [0, %d]", i, nu, RAYZ_KAT_IN_STRIDE - (at + 1));
             }
-            if (op == RAYZ_KAT_BOX_HIT) { // the padding the scene upload gives a box: S = this ray's origin, B = this box
+            if (op == RAYZ_KAT_BOX_HIT) { // the box as a scene upload would hold it (S = this ray's origin, B = this box), in the format a[26] names
+                rayz_bvh::Box bx;
                 double B = 0;
-                for (int k = 0; k < 6; ++k) B = std::max(B, std::fabs(a[k]));
-                a[14] = kBoxPadUlps * unit_roundoff<float>() * std::max(norm3(a + 6), B);
+                for (int k = 0; k < 3; ++k) bx.lo[k] = a[k], bx.hi[k] = a[3 + k], B = std::max({B, std::fabs(a[k]), std::fabs(a[3 + k])});
+                if (a[26] != 0.0) { // f32 planes
+                    const double pad = kBoxPadUlps * unit_roundoff<float>() * std::max(norm3(a + 6), B);
+                    for (int k = 0; k < 3; ++k) {
+                        a[14 + k] = (double)rayz_bvh::roundDown<float>(bx.lo[k] - pad), a[17 + k] = (double)rayz_bvh::roundUp<float>(bx.hi[k] + pad);
+                        a[20 + k] = 0.0, a[23 + k] = 1.0;
+                    }
+                } else { // 16-bit plane indices on the grid over this box
+                    double pad = kBoxPadUlps * unit_roundoff<float>() * (std::max(norm3(a + 6), B) + 2.0 * B);
+                    const rayz_bvh::PlaneGrid g = rayz_bvh::PlaneGrid::over(bx.lo, bx.hi, 2.0 * pad);
+                    pad = kBoxPadUlps * unit_roundoff<float>() * (std::max(norm3(a + 6), B) + g.extent);
+                    uint32_t w[3];
+                    g.quantize(bx, pad, w);
+                    for (int k = 0; k < 3; ++k) a[14 + k] = w[k] & 0xffffu, a[17 + k] = w[k] >> 16, a[20 + k] = g.glo[k], a[23 + k] = g.cell[k];
+                }
             }
             if (op == RAYZ_KAT_SCAN_DISCS) { // the padded squares the scan streams would hold for these four spheres
                 double S = norm3(a + 20);

@@ -138,6 +138,7 @@ def random_boxes(rng, n):
     d = (aim - o) * rng.uniform(0.1, 3, (n, 1))
     rec[:, 0:3], rec[:, 3:6], rec[:, 6:9], rec[:, 9:12] = f32r(lo), f32r(hi), f32r(o), f32r(d)
     rec[:, 12], rec[:, 13] = 1e-3, np.where(rng.random(n) < 0.5, np.inf, rng.uniform(0.1, 3, n))
+    rec[:, 26] = np.arange(n) % 2  # either node record format (include/rayz_hip.h: RAYZ_KAT_BOX_HIT); no draw: the sets after this one stay what they were
     return rec
 
 
@@ -161,6 +162,7 @@ def axis_parallel_boxes(rng, n):
         d[i, ax] = rng.choice([0.0, -0.0], len(ax))
     rec[:, 0:3], rec[:, 3:6], rec[:, 6:9], rec[:, 9:12] = lo, hi, o, d
     rec[:, 12], rec[:, 13] = 1e-3, np.inf
+    rec[:, 26] = np.arange(n) % 2  # either node record format
     # geometric truth: a parallel axis is satisfied iff o lies strictly inside the slab; the others by exact intervals
     with np.errstate(divide="ignore", invalid="ignore"):
         a, b = (lo - o) / d, (hi - o) / d
