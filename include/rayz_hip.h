@@ -191,7 +191,8 @@ typedef enum RayzDebugKnob {
     RAYZ_DEBUG_LDS_PAD = 6,    /* BVH kernels: unused bytes added to the workgroup's LDS request (occupancy experiments) */
     RAYZ_DEBUG_BVH_TOP_ORDER = 7, /* which inner nodes the LDS top holds: 0 = by box surface area from the root (default), 1 = breadth-first */
     RAYZ_DEBUG_BVH_NODES = 8,     /* node record format of trees built from now on: 0 = by tree size (default), 1 = f32 planes (64 B), 2 = 16-bit plane indices (32 B) */
-    RAYZ_DEBUG_KNOBS = 9
+    RAYZ_DEBUG_BVH_SPLIT = 9,     /* how trees built from now on split a node: 0 = surface-area heuristic (default), 1 = the reference's median split */
+    RAYZ_DEBUG_KNOBS = 10
 } RayzDebugKnob;
 int rayz_hip_debug_set(uint32_t knob, long long value);
 

@@ -99,6 +99,115 @@ inline void build(std::vector<Item>& h, size_t si, size_t ei, FlatBvh& out, uint
     }
     out.nodes[me].skip = (uint32_t)out.nodes.size();
 }
+
+// The tree the GPU walks need not be the reference's — the nearest hit does not depend on how the hittables are
+// organised — so it is built for FEWER BOX TESTS: greedy surface-area heuristic, cost(split) = area(L)·n(L) + area(R)·n(R)
+// over the hittables sorted by box centre on each axis (every split position for up to kSweepMax hittables, 64 bins of
+// the centre range above), leaves of ≤ 2 as the device's leaf descriptor holds them.  Deterministic (stable sorts, ties
+// to the lower axis and the lower position).  `budget` = levels left: the per-lane stacks in LDS are sized by the depth, so
+// a node that could no longer finish with halvings alone is split at its median instead (never deeper than the reference's
+// tree + kSahExtraDepth).
+constexpr size_t kSweepMax = 4096;
+constexpr uint32_t kSahBins = 64, kSahExtraDepth = 4;
+inline double halfArea(const Box& b) {
+    const double x = b.hi[0] - b.lo[0], y = b.hi[1] - b.lo[1], z = b.hi[2] - b.lo[2];
+    return x * y + y * z + z * x;
+}
+inline uint32_t levelsFor(size_t n) { // depth of a halving tree over n hittables with leaves of <= 2 (root = 1)
+    uint32_t d = 1;
+    while (n > 2) n = n - n / 2, ++d;
+    return d;
+}
+inline void buildSah(std::vector<Item>& h, size_t si, size_t ei, FlatBvh& out, uint32_t depth, uint32_t budget) {
+    const size_t me = out.nodes.size();
+    out.nodes.push_back(FlatNode{});
+    out.depth = std::max(out.depth, depth);
+    Box bb;
+    for (size_t i = si; i < ei; ++i) bb.enclose(h[i].box);
+    const size_t n = ei - si;
+    out.nodes[me].box = bb;
+    if (n <= 2) {
+        out.nodes[me].first = (uint32_t)si;
+        out.nodes[me].count = (uint32_t)n;
+        out.nodes[me].skip = (uint32_t)out.nodes.size();
+        return;
+    }
+    auto centre = [](const Item& it, int ax) { return it.box.lo[ax] + it.box.hi[ax]; }; // (twice the centre)
+    size_t mid = si + n / 2;
+    int best_ax = -1;
+    if (levelsFor(n) < budget) { // room for an uneven split
+        double best = std::numeric_limits<double>::infinity();
+        size_t best_pos = 0;
+        std::vector<double> right_area;
+        for (int ax = 0; ax < 3; ++ax) {
+            double c0 = std::numeric_limits<double>::infinity(), c1 = -c0;
+            for (size_t i = si; i < ei; ++i) c0 = std::fmin(c0, centre(h[i], ax)), c1 = std::fmax(c1, centre(h[i], ax));
+            if (!(c1 > c0)) continue;
+            if (n <= kSweepMax) {
+                std::stable_sort(h.begin() + (ptrdiff_t)si, h.begin() + (ptrdiff_t)ei,
+                                 [&](const Item& a, const Item& b) { return centre(a, ax) < centre(b, ax); });
+                right_area.assign(n + 1, 0.0);
+                Box acc;
+                for (size_t i = n; i-- > 1;) acc.enclose(h[si + i].box), right_area[i] = halfArea(acc);
+                acc = Box();
+                for (size_t i = 1; i < n; ++i) { // split: [0, i) | [i, n)
+                    acc.enclose(h[si + i - 1].box);
+                    const double cost = halfArea(acc) * (double)i + right_area[i] * (double)(n - i);
+                    if (cost < best) best = cost, best_ax = ax, best_pos = i;
+                }
+            } else {
+                Box bins[kSahBins];
+                size_t cnt[kSahBins] = {};
+                const double scale = (double)kSahBins / (c1 - c0);
+                auto bin_of = [&](const Item& it) { return std::min<size_t>(kSahBins - 1, (size_t)((centre(it, ax) - c0) * scale)); };
+                for (size_t i = si; i < ei; ++i) bins[bin_of(h[i])].enclose(h[i].box), cnt[bin_of(h[i])]++;
+                double ra[kSahBins + 1] = {};
+                size_t rn[kSahBins + 1] = {};
+                Box acc;
+                for (size_t b = kSahBins; b-- > 1;) acc.enclose(bins[b]), rn[b] = rn[b + 1] + cnt[b], ra[b] = rn[b] ? halfArea(acc) : 0.0;
+                acc = Box();
+                size_t ln = 0;
+                for (size_t b = 1; b < kSahBins; ++b) { // split: bins [0, b) | [b, kSahBins)
+                    acc.enclose(bins[b - 1]), ln += cnt[b - 1];
+                    if (ln == 0 || rn[b] == 0) continue;
+                    const double cost = halfArea(acc) * (double)ln + ra[b] * (double)rn[b];
+                    if (cost < best) best = cost, best_ax = ax, best_pos = kSweepMax + b; // (a bin, not a position)
+                }
+            }
+        }
+        if (best_ax >= 0) {
+            const int ax = best_ax;
+            if (best_pos > kSweepMax && n > kSweepMax) {
+                double c0 = std::numeric_limits<double>::infinity(), c1 = -c0;
+                for (size_t i = si; i < ei; ++i) c0 = std::fmin(c0, centre(h[i], ax)), c1 = std::fmax(c1, centre(h[i], ax));
+                const double scale = (double)kSahBins / (c1 - c0);
+                const size_t b = best_pos - kSweepMax;
+                mid = (size_t)(std::stable_partition(h.begin() + (ptrdiff_t)si, h.begin() + (ptrdiff_t)ei,
+                                                     [&](const Item& it) {
+                                                         return std::min<size_t>(kSahBins - 1, (size_t)((centre(it, ax) - c0) * scale)) < b;
+                                                     }) -
+                               h.begin());
+            } else {
+                std::stable_sort(h.begin() + (ptrdiff_t)si, h.begin() + (ptrdiff_t)ei,
+                                 [&](const Item& a, const Item& b) { return centre(a, ax) < centre(b, ax); });
+                mid = si + best_pos;
+            }
+        }
+    }
+    if (best_ax < 0) { // out of levels, or every centre coincides: halve along the longest axis of the centres' range
+        Box cb;
+        for (size_t i = si; i < ei; ++i)
+            for (int k = 0; k < 3; ++k) cb.lo[k] = std::fmin(cb.lo[k], centre(h[i], k)), cb.hi[k] = std::fmax(cb.hi[k], centre(h[i], k));
+        const int ax = cb.longestAxis();
+        std::stable_sort(h.begin() + (ptrdiff_t)si, h.begin() + (ptrdiff_t)ei,
+                         [&](const Item& a, const Item& b) { return centre(a, ax) < centre(b, ax); });
+        mid = si + n / 2;
+    }
+    out.nodes[me].count = 0;
+    buildSah(h, si, mid, out, depth + 1, budget - 1);
+    buildSah(h, mid, ei, out, depth + 1, budget - 1);
+    out.nodes[me].skip = (uint32_t)out.nodes.size();
+}
 } // namespace detail
 
 constexpr size_t kMaxBig = 8;   // oversized hittables kept out of the tree, at most
@@ -113,8 +222,9 @@ constexpr size_t kMinTree = 32; // .. and only while the tree keeps more than th
 // (the r = 1000 ground sphere of randomBouncing, src/rayz.zig:58-74) makes the box of every one of its ~14 ancestors
 // cover the whole scene, so every ray visits them all; kept out of the tree it is tested once per segment instead and
 // the remaining boxes are tight.  The nearest hit does not depend on how the hittables are organised.
+// sah = true (the tree the GPU walks, again): split by surface-area heuristic instead (detail::buildSah above).
 inline FlatBvh build(const std::vector<RayzSphere>& spheres, const std::vector<RayzTriangle>& triangles,
-                     bool peel_oversized = false) {
+                     bool peel_oversized = false, bool sah = false) {
     FlatBvh out;
     if (spheres.empty() && triangles.empty()) return out;
     std::vector<detail::Item> h(spheres.size() + triangles.size());
@@ -146,7 +256,8 @@ inline FlatBvh build(const std::vector<RayzSphere>& spheres, const std::vector<R
             h.erase(h.begin() + (ptrdiff_t)worst); // keeps pool order among the rest
         }
     }
-    detail::build(h, 0, h.size(), out, 1);
+    if (sah) detail::buildSah(h, 0, h.size(), out, 1, detail::levelsFor(h.size()) + detail::kSahExtraDepth);
+    else detail::build(h, 0, h.size(), out, 1);
     out.order.resize(h.size());
     for (size_t i = 0; i < h.size(); ++i) out.order[i] = h[i].pool;
     return out;

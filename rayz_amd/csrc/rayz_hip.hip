@@ -416,7 +416,7 @@ void ensure_bvh(RayzScene* s) {
 void ensure_bvh_dev(RayzScene* s) {
     if (!s->bvh_dev_built) {
         // RAYZ_DEBUG_BVH_PEEL = 0 (measurement only): walk the reference's full tree
-        s->bvh_dev = rayz_bvh::build(s->spheres, s->triangles, tuning(RAYZ_DEBUG_BVH_PEEL, 1) != 0);
+        s->bvh_dev = rayz_bvh::build(s->spheres, s->triangles, tuning(RAYZ_DEBUG_BVH_PEEL, 1) != 0, tuning(RAYZ_DEBUG_BVH_SPLIT, 0) == 0);
         s->bvh_dev_built = true;
     }
 }
