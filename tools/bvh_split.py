@@ -22,7 +22,7 @@ def bench(t, spp, reps=3):
     return st.primary_rays / best / 1e3, st.node_tests / st.segments, st.sphere_tests / st.segments, out.clone()
 scenes = [("config2", lambda: tracer.randomBouncing(1920, seed=42), 128), ("config3", lambda: tracer.randomBouncing(1920, -50, 50, seed=42), 256),
           ("grid 150", lambda: tracer.randomBouncing(1920, -150, 150, seed=42), 128), ("config5 mesh", lambda: tracer.triangleMesh(1920, 224, seed=1), 128)]
-for name, make, spp in scenes:
+for name, make, spp in (scenes[:int(sys.argv[1])] if len(sys.argv) > 1 else scenes):
     res = {}
     for split in (1, 0):
         render.debug_set(capi.DEBUG_BVH_SPLIT, split)
