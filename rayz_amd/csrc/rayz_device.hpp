@@ -118,6 +118,7 @@ template <class R> struct TraceArgs {
     const uint32_t* chunk_start; // [chunks_per_px + 1] first sample of every chunk of a pixel (the chunk schedule)
     uint32_t chunks_per_px;
     uint32_t tile_rows, shard_index, shard_count, shard_pixels;
+    uint32_t tiled_pixels;   // the first this-many local pixels are dealt to the queue as 8x8 tiles (place_item)
     uint32_t total_items;
     uint32_t bvh_keep;       // BVH kernel: keep_active | keep_stepping << 8 (see trace_kernel_bvh)
     uint32_t bvh_top_words;   // BVH kernel: u32s of LDS taken by the copy of the tree's top (the per-lane stacks follow)
@@ -828,6 +829,26 @@ template <class R> __device__ __forceinline__ void path_init(PathState<R>& p) {
 // instead of 5.7 Gsamples/s at 64 spp): it reserves kQueueGrab consecutive items at a time and hands them to its lanes
 // as they fall idle (ballot → prefix rank), touching the counter again only when the reserve runs out.  All fields are
 // wave-uniform.  Which lane traces an item never affects the image.
+// Which pixel and chunk a queue entry is: entry e = k · shard_pixels + i covers chunk k of the i-th pixel dealt.  Pixels are
+// dealt in 8x8 TILES of the shard's local rows (the first A.tiled_pixels of them: whole tiles only, the rest row by row), so
+// that the 64 items a wave grabs together are neighbours in both directions: their primary rays walk the same part of the
+// tree (+1 … 2.6 % through the BVH, profiles/r03/tree/tile8.log).  The sums are stored by ROW-MAJOR pixel as before: `item`
+// becomes k · shard_pixels + (local row · width + column), what resolve_kernel reads.  Returns k.
+template <class R> __device__ __forceinline__ uint32_t place_item(const TraceArgs<R>& A, uint32_t& item, uint32_t& px, uint32_t& py) {
+    const uint32_t k = item / A.shard_pixels;
+    uint32_t lp = item - k * A.shard_pixels;
+    if (lp < A.tiled_pixels) {
+        const uint32_t tile = lp >> 6, w8 = A.width >> 3, trow = tile / w8, tcol = tile - trow * w8;
+        lp = (trow * 8u + ((lp >> 3) & 7u)) * A.width + tcol * 8u + (lp & 7u);
+        item = k * A.shard_pixels + lp;
+    }
+    const uint32_t lr = lp / A.width;
+    px = lp - lr * A.width;
+    const uint32_t tl = lr / A.tile_rows, within = lr - tl * A.tile_rows;
+    py = (tl * A.shard_count + A.shard_index) * A.tile_rows + within;
+    return k;
+}
+
 struct WaveQueue {
     uint32_t base = 0, count = 0; // the wave's reserve: items base .. base+count-1
     bool drained = false;         // the last reservation reached the end of the queue
@@ -877,11 +898,7 @@ __device__ __forceinline__ void path_refill(PathState<R>& p, const TraceArgs<R>&
         if (queue_pop<R>(A, wq, lane, !p.alive && !p.has_item && !queue_empty<R>(wq, A), got_item)) {
             p.item = got_item;
             p.has_item = true;
-            const uint32_t k = p.item / A.shard_pixels, lp = p.item - k * A.shard_pixels;
-            const uint32_t lr = lp / A.width;
-            p.px = lp - lr * A.width;
-            const uint32_t tl = lr / A.tile_rows, within = lr - tl * A.tile_rows;
-            p.py = (tl * A.shard_count + A.shard_index) * A.tile_rows + within;
+            const uint32_t k = place_item<R>(A, p.item, p.px, p.py);
             p.s_cur = A.chunk_start[k];
             p.s_end = A.chunk_start[k + 1];
             p.acc = {R(0), R(0), R(0)};
@@ -1415,11 +1432,7 @@ void trace_kernel_bvh(const TraceArgs<R> A) {
             if (queue_pop<R>(A, wq, lane, !alive && !has_item && !queue_empty<R>(wq, A), got_item)) {
                 item = got_item;
                 has_item = true;
-                const uint32_t k = item / A.shard_pixels, lp = item - k * A.shard_pixels;
-                const uint32_t lr = lp / A.width;
-                px = lp - lr * A.width;
-                const uint32_t tl = lr / A.tile_rows, within = lr - tl * A.tile_rows;
-                py = (tl * A.shard_count + A.shard_index) * A.tile_rows + within;
+                const uint32_t k = place_item<R>(A, item, px, py);
                 s_cur = A.chunk_start[k];
                 s_end = A.chunk_start[k + 1];
                 acc = {R(0), R(0), R(0)};
@@ -1697,11 +1710,7 @@ template <class R, bool QUANT> __global__ __launch_bounds__(256, RAYZ_BVH2_WAVES
                 if (queue_pop<R>(A, wq, lane, need, got_item)) {
                     c.item = got_item;
                     c.has_item = true;
-                    const uint32_t k = c.item / A.shard_pixels, lp = c.item - k * A.shard_pixels;
-                    const uint32_t lr = lp / A.width;
-                    c.px = lp - lr * A.width;
-                    const uint32_t tl = lr / A.tile_rows, within = lr - tl * A.tile_rows;
-                    c.py = (tl * A.shard_count + A.shard_index) * A.tile_rows + within;
+                    const uint32_t k = place_item<R>(A, c.item, c.px, c.py);
                     c.s_cur = A.chunk_start[k];
                     c.s_end = A.chunk_start[k + 1];
                     c.acc = {R(0), R(0), R(0)};

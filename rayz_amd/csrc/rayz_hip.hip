@@ -843,6 +843,7 @@ int render_impl(RayzScene* s, const DeviceCtx& ctx, SceneBuffers<R>& b, const Ra
     A.shard_index = p->shard_index;
     A.shard_count = p->shard_count ? p->shard_count : 1u;
     A.shard_pixels = (uint32_t)shard_pixels64;
+    A.tiled_pixels = p->width % 8 == 0 ? (uint32_t)((uint64_t)(rows / 8 * 8) * p->width) : 0u; // whole 8x8 tiles of the local rows (place_item)
     A.total_items = (uint32_t)items64;
     A.queue_grab = (uint32_t)std::max(1ll, tuning(RAYZ_DEBUG_QUEUE_GRAB, kQueueGrab));
     // Which walk: one path per lane (trace_kernel_bvh).  The two-paths-per-lane form (trace_kernel_bvh2, f32 only) is kept
