@@ -834,10 +834,11 @@ template <class R> __device__ __forceinline__ void path_init(PathState<R>& p) {
 // that the 64 items a wave grabs together are neighbours in both directions: their primary rays walk the same part of the
 // tree (+1 … 2.6 % through the BVH, profiles/r03/tree/tile8.log).  The sums are stored by ROW-MAJOR pixel as before: `item`
 // becomes k · shard_pixels + (local row · width + column), what resolve_kernel reads.  Returns k.
-template <class R> __device__ __forceinline__ uint32_t place_item(const TraceArgs<R>& A, uint32_t& item, uint32_t& px, uint32_t& py) {
+// (kTiled = false — the flat-list kernel, whose lanes all scan the same list: rows as they come.)
+template <class R, bool kTiled> __device__ __forceinline__ uint32_t place_item(const TraceArgs<R>& A, uint32_t& item, uint32_t& px, uint32_t& py) {
     const uint32_t k = item / A.shard_pixels;
     uint32_t lp = item - k * A.shard_pixels;
-    if (lp < A.tiled_pixels) {
+    if (kTiled && lp < A.tiled_pixels) {
         const uint32_t tile = lp >> 6, w8 = A.width >> 3, trow = tile / w8, tcol = tile - trow * w8;
         lp = (trow * 8u + ((lp >> 3) & 7u)) * A.width + tcol * 8u + (lp & 7u);
         item = k * A.shard_pixels + lp;
@@ -898,7 +899,7 @@ __device__ __forceinline__ void path_refill(PathState<R>& p, const TraceArgs<R>&
         if (queue_pop<R>(A, wq, lane, !p.alive && !p.has_item && !queue_empty<R>(wq, A), got_item)) {
             p.item = got_item;
             p.has_item = true;
-            const uint32_t k = place_item<R>(A, p.item, p.px, p.py);
+            const uint32_t k = place_item<R, false>(A, p.item, p.px, p.py);
             p.s_cur = A.chunk_start[k];
             p.s_end = A.chunk_start[k + 1];
             p.acc = {R(0), R(0), R(0)};
@@ -1432,7 +1433,7 @@ void trace_kernel_bvh(const TraceArgs<R> A) {
             if (queue_pop<R>(A, wq, lane, !alive && !has_item && !queue_empty<R>(wq, A), got_item)) {
                 item = got_item;
                 has_item = true;
-                const uint32_t k = place_item<R>(A, item, px, py);
+                const uint32_t k = place_item<R, true>(A, item, px, py);
                 s_cur = A.chunk_start[k];
                 s_end = A.chunk_start[k + 1];
                 acc = {R(0), R(0), R(0)};
@@ -1710,7 +1711,7 @@ template <class R, bool QUANT> __global__ __launch_bounds__(256, RAYZ_BVH2_WAVES
                 if (queue_pop<R>(A, wq, lane, need, got_item)) {
                     c.item = got_item;
                     c.has_item = true;
-                    const uint32_t k = place_item<R>(A, c.item, c.px, c.py);
+                    const uint32_t k = place_item<R, true>(A, c.item, c.px, c.py);
                     c.s_cur = A.chunk_start[k];
                     c.s_end = A.chunk_start[k + 1];
                     c.acc = {R(0), R(0), R(0)};
