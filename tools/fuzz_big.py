@@ -10,6 +10,8 @@ from oracle import binding as oracle
 from rayz_amd import capi, render, tracer
 
 render.init(0); oracle.load()
+if 'nodes16' in sys.argv:  # force the 32-byte node records (16-bit plane indices) however small the tree
+    sys.argv.remove('nodes16'); render.debug_set(capi.DEBUG_BVH_NODES, 2)
 
 
 def big_scene(seed):

@@ -9,7 +9,9 @@ from oracle import binding as oracle
 from rayz_amd import capi, render
 from test_fuzz_gpu import random_scene, axis_scene
 
-render.init(0); oracle.load()
+render.init(0)
+if 'nodes16' in sys.argv:  # force the 32-byte node records (16-bit plane indices) however small the tree
+    sys.argv.remove('nodes16'); render.debug_set(capi.DEBUG_BVH_NODES, 2); oracle.load()
 first, count = int(sys.argv[1]), int(sys.argv[2])
 bad = 0
 for seed in range(first, first + count):
