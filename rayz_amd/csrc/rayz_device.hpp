@@ -1275,10 +1275,15 @@ __device__ __forceinline__ void bvh_node_step(const DevScene<R>& sc, const f4* n
     const unsigned long long ml = __ballot(hl), mr = __ballot(hr), mlt = __ballot(tr < tl);
     const unsigned long long swap = mr & (~ml | mlt), both = ml & mr, none = ~(ml | mr);
     // Nearer child first (a child that was not hit may ride along as `near` or `far`: `none` and `both` decide what is used)
-    const uint32_t near = mask_select(swap, r, l), far = mask_select(swap, l, r);
+    const uint32_t near = mask_select(swap, r, l);
+    uint32_t far = mask_select(swap, l, r);
+    q.cur = mask_select(none, q.top, near); // nothing hit => nothing pushed: the entry read ahead IS the top
+    // The push goes AFTER that select in program order (the empty asm makes `far` look computed from q.cur): the compiler
+    // guards the select's read of q.top — the previous step's read-ahead, long since back behind the node fetch — with
+    // s_waitcnt lgkmcnt(0), and a store issued before it would put an LDS round trip into every step's dependent chain.
+    asm volatile("" : "+v"(far) : "v"(q.cur));
     stack[WG * (q.sp + 1u)] = far; // lands above the top unless both were hit
     const uint32_t sp = mask_add(q.sp, both);
-    q.cur = mask_select(none, q.top, near); // nothing hit => nothing pushed: the entry read ahead IS the top
     q.sp = mask_sub(sp, none); // popping the sentinel leaves sp at −1: the lane holds kBvhDone and steps no more until
                                // bvh_begin (its read-ahead below lands in the guard row under the stack)
     q.top = stack[WG * q.sp]; // read ahead for the NEXT pop — after the store above (LDS keeps a wave's order), consumed

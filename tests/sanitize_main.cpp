@@ -80,6 +80,36 @@ int main() {
                     cluster.big.size());
         bad |= !ground_only || !cluster.big.empty() || cluster.order.size() != cl.size();
     }
+    { // the tree the GPU walks (surface-area split): every hittable in exactly one leaf of <= 2, skip links consistent, depth
+      // within the budget the LDS stacks are sized for — small pools, the 10k grid (sweep) and a pool above kSweepMax (bins)
+        for (int g : {2, 11, 50, 40}) {
+            rayz::Tracer rb = g == 40 ? rayz::triangleMesh(32, 60, &seed) : rayz::randomBouncing(32, -g, g, &seed);
+            const rayz::Tracer::Flat fr = rb.flatten();
+            const rayz_bvh::FlatBvh tr = rayz_bvh::build(fr.spheres, fr.triangles, true, true);
+            const size_t n = fr.spheres.size() + fr.triangles.size();
+            std::vector<int> seen(n, 0);
+            for (uint32_t b : tr.big) seen[b]++;
+            bool ok = tr.depth <= rayz_bvh::detail::levelsFor(n - tr.big.size()) + rayz_bvh::detail::kSahExtraDepth;
+            for (size_t i = 0; i < tr.nodes.size(); ++i) {
+                const rayz_bvh::FlatNode& nd = tr.nodes[i];
+                ok = ok && nd.skip > i && nd.skip <= tr.nodes.size() && nd.count <= 2;
+                for (uint32_t k = 0; k < nd.count; ++k) {
+                    const uint32_t h = tr.order[nd.first + k];
+                    seen[h]++;
+                    const rayz_bvh::Box hb = h < fr.spheres.size() ? rayz_bvh::sphereBox(fr.spheres[h]) : rayz_bvh::triangleBox(fr.triangles[h - fr.spheres.size()]);
+                    for (int a = 0; a < 3; ++a) ok = ok && hb.lo[a] >= nd.box.lo[a] && hb.hi[a] <= nd.box.hi[a];
+                }
+                if (nd.count == 0) { // children inside the parent, right child where the left subtree ends
+                    const rayz_bvh::FlatNode &l = tr.nodes[i + 1], &r = tr.nodes[l.skip];
+                    ok = ok && l.skip < nd.skip && r.skip == nd.skip;
+                    for (int a = 0; a < 3; ++a) ok = ok && std::fmin(l.box.lo[a], r.box.lo[a]) == nd.box.lo[a] && std::fmax(l.box.hi[a], r.box.hi[a]) == nd.box.hi[a];
+                }
+            }
+            for (int c : seen) ok = ok && c == 1;
+            std::printf("sah tree over %zu hittables: %zu nodes, depth %u, %s\n", n, tr.nodes.size(), tr.depth, ok ? "ok" : "BROKEN");
+            bad |= !ok;
+        }
+    }
     FILE* f = std::fopen("/dev/null", "w");
     t1.img.writePPM(f);
     std::fclose(f);

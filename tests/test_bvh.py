@@ -156,6 +156,36 @@ def test_gpu_bvh_parity_random_bouncing(gpu, oracle, prec):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("scene", ["spheres", "mesh"])
+def test_gpu_image_does_not_depend_on_the_walked_tree_or_its_record_format(gpu, oracle, scene):
+    """The tree the GPU walks is the product's own (surface-area split, bvh_build.hpp) in one of two record formats (f32
+    planes / 16-bit plane indices, DevScene::bvh_nodes): every combination — and the reference's median split — gives the
+    oracle's image bit for bit, both precisions; the SAH tree needs fewer box tests."""
+    t = tracer.randomBouncing(128, -30, 30, seed=42) if scene == "spheres" else tracer.triangleMesh(128, 40, seed=3)
+    t.samples_per_px = 6
+    tests = {}
+    try:
+        for prec in (capi.PRECISION_F32, capi.PRECISION_F64):
+            t.set_gpu(render_seed=9, traversal=capi.TRAVERSAL_BVH, precision=prec)
+            sd, cam, p = t.scene_desc(), t.camera_desc(), t.params()
+            want, ost = oracle.render_b(sd, cam, p)
+            for split in (0, 1):
+                for fmt in (1, 2):
+                    gpu.debug_set(capi.DEBUG_BVH_SPLIT, split)
+                    gpu.debug_set(capi.DEBUG_BVH_NODES, fmt)
+                    got, gst = gpu.render_host(sd, cam, p)  # (a fresh scene per call: the knobs act when the tree is built)
+                    assert_images_equal(got, want, f"{scene} precision {prec} split {split} node format {fmt}")
+                    assert gst.segments == ost.segments
+                    tests[(prec, split, fmt)] = gst.node_tests
+        for prec in (capi.PRECISION_F32, capi.PRECISION_F64):
+            assert tests[(prec, 0, 1)] < 0.97 * tests[(prec, 1, 1)]  # SAH: fewer box tests than the median split
+            assert abs(tests[(prec, 0, 2)] - tests[(prec, 0, 1)]) < 0.02 * tests[(prec, 0, 1)]  # index boxes: a cell larger at most
+    finally:
+        gpu.debug_set(capi.DEBUG_BVH_SPLIT, 0)
+        gpu.debug_set(capi.DEBUG_BVH_NODES, 0)
+
+
+@pytest.mark.gpu
 def test_gpu_bvh_parity_10k_and_equals_flat_list(gpu, oracle):
     t = tracer.randomBouncing(128, -50, 50, seed=42)
     t.samples_per_px = 8
