@@ -1308,14 +1308,12 @@ __device__ __forceinline__ bool leaf_reject_test(const RayBasis<float>& b, float
 // Phase L — entry k of a parked leaf: a triangle is decided here (R arithmetic only); a sphere gets the reject
 // test in R and, if its line meets the sphere, is parked as a candidate (slot + 1) for phase C.
 template <class R>
-__device__ __forceinline__ uint32_t bvh_leaf_entry(const DevScene<R>& sc, BvhQuery<R>& q, uint32_t leaf, uint32_t k, V<R> o,
-                                                   V<R> d, V<R> ud, R time, R tmin) {
+__device__ __forceinline__ uint32_t bvh_leaf_eval(const DevScene<R>& sc, BvhQuery<R>& q, uint32_t leaf, uint32_t k, typename VecOf<R>::type c,
+                                                  typename VecOf<R>::type v, V<R> o, V<R> d, V<R> ud, R time, R tmin) {
     typedef typename VecOf<R>::type r4;
     const uint32_t slot = (leaf >> 4) + k;
-    const r4* rec = sc.bvh_leaf + (size_t)sc.bvh_leaf_stride * slot;
-    const r4 c = rec[0], v = rec[1];
     if ((leaf >> (2u + k)) & 1u) { // triangle
-        const r4 e2 = rec[2];
+        const r4 e2 = sc.bvh_leaf[(size_t)sc.bvh_leaf_stride * slot + 2];
         const V<R> v0{c.x, c.y, c.z}, e1{v.x, v.y, v.z}, ee2{e2.x, e2.y, e2.z};
         tri_accept<R>(tri_filter<R>(v0, e1, ee2, o, d), v0, e1, ee2, o, d, tmin, (int)bits(c.w), q.tbest, q.ibest);
         return 0u;
@@ -1325,6 +1323,32 @@ __device__ __forceinline__ uint32_t bvh_leaf_entry(const DevScene<R>& sc, BvhQue
     const RayBasis<float> b = q.lb.get(ud, o);
     return leaf_reject_test(b, (float)time, V<float>{(float)c.x, (float)c.y, (float)c.z}, V<float>{(float)v.x, (float)v.y, (float)v.z}, (float)c.w)
                ? slot + 1u : 0u;
+}
+template <class R>
+__device__ __forceinline__ uint32_t bvh_leaf_entry(const DevScene<R>& sc, BvhQuery<R>& q, uint32_t leaf, uint32_t k, V<R> o,
+                                                   V<R> d, V<R> ud, R time, R tmin) {
+    typedef typename VecOf<R>::type r4;
+    const r4* rec = sc.bvh_leaf + (size_t)sc.bvh_leaf_stride * ((leaf >> 4) + k);
+    return bvh_leaf_eval<R>(sc, q, leaf, k, rec[0], rec[1], o, d, ud, time, tmin);
+}
+// Both entries of a parked leaf (phase L): their records are FETCHED together — entry 1's loads do not wait for entry 0's
+// test (two dependent memory round trips per leaf phase otherwise); a leaf of one repeats entry 0's address, its second
+// result is dropped.  R = float only: the f64 kernel has no eight registers to spare and tests one entry after the other.
+template <class R>
+__device__ __forceinline__ void bvh_leaf_pair(const DevScene<R>& sc, BvhQuery<R>& q, uint32_t leaf, V<R> o, V<R> d, V<R> ud, R time, R tmin,
+                                              uint32_t& cand0, uint32_t& cand1) {
+    typedef typename VecOf<R>::type r4;
+    const bool two = (leaf & 3u) > 1u;
+    if constexpr (sizeof(R) == 4) {
+        const r4* rec = sc.bvh_leaf + (size_t)sc.bvh_leaf_stride * (leaf >> 4);
+        const r4* rec1 = rec + (two ? sc.bvh_leaf_stride : 0u);
+        const r4 c0 = rec[0], v0 = rec[1], c1 = rec1[0], v1 = rec1[1];
+        cand0 = bvh_leaf_eval<R>(sc, q, leaf, 0u, c0, v0, o, d, ud, time, tmin);
+        if (two) cand1 = bvh_leaf_eval<R>(sc, q, leaf, 1u, c1, v1, o, d, ud, time, tmin);
+    } else {
+        cand0 = bvh_leaf_entry<R>(sc, q, leaf, 0u, o, d, ud, time, tmin);
+        if (two) cand1 = bvh_leaf_entry<R>(sc, q, leaf, 1u, o, d, ud, time, tmin);
+    }
 }
 
 // Phase C — the f64 quadratic of a parked sphere candidate (same arithmetic as narrow_phase()).
@@ -1521,8 +1545,7 @@ void trace_kernel_bvh(const TraceArgs<R> A) {
             if (parked) { // phase L
                 const uint32_t leaf = q.cur & ~kBvhLeafFlag;
                 sphere_tests += leaf & 3u;
-                cand0 = bvh_leaf_entry<R>(A.sc, q, leaf, 0u, o, d, ud, time, A.tmin);
-                if ((leaf & 3u) > 1u) cand1 = bvh_leaf_entry<R>(A.sc, q, leaf, 1u, o, d, ud, time, A.tmin);
+                bvh_leaf_pair<R>(A.sc, q, leaf, o, d, ud, time, A.tmin, cand0, cand1);
                 bvh_pop<R, kBvhWg>(q, stack);
             }
             RAYZ_PROF_T(2)
