@@ -1307,6 +1307,7 @@ __device__ __forceinline__ bool leaf_reject_test(const RayBasis<float>& b, float
 
 // Phase L — entry k of a parked leaf: a triangle is decided here (R arithmetic only); a sphere gets the reject
 // test in R and, if its line meets the sphere, is parked as a candidate (slot + 1) for phase C.
+// (a sphere's pool index rides in its record's last word, v.w: phase C takes it from there — see bvh_leaf_pair)
 template <class R>
 __device__ __forceinline__ uint32_t bvh_leaf_eval(const DevScene<R>& sc, BvhQuery<R>& q, uint32_t leaf, uint32_t k, typename VecOf<R>::type c,
                                                   typename VecOf<R>::type v, V<R> o, V<R> d, V<R> ud, R time, R tmin) {
@@ -1334,9 +1335,12 @@ __device__ __forceinline__ uint32_t bvh_leaf_entry(const DevScene<R>& sc, BvhQue
 // Both entries of a parked leaf (phase L): their records are FETCHED together — entry 1's loads do not wait for entry 0's
 // test (two dependent memory round trips per leaf phase otherwise); a leaf of one repeats entry 0's address, its second
 // result is dropped.  R = float only: the f64 kernel has no eight registers to spare and tests one entry after the other.
+// The candidates' POOL indices (the tie rule's and the hit record's key) come back too: they ride in the records just
+// fetched (v.w), and phase C would otherwise fetch them again — after its roots, when a root is accepted: the compiler
+// sinks that load into the branch, a second memory round trip inside the phase.
 template <class R>
 __device__ __forceinline__ void bvh_leaf_pair(const DevScene<R>& sc, BvhQuery<R>& q, uint32_t leaf, V<R> o, V<R> d, V<R> ud, R time, R tmin,
-                                              uint32_t& cand0, uint32_t& cand1) {
+                                              uint32_t& cand0, uint32_t& cand1, int& pool0, int& pool1) {
     typedef typename VecOf<R>::type r4;
     const bool two = (leaf & 3u) > 1u;
     if constexpr (sizeof(R) == 4) {
@@ -1344,19 +1348,35 @@ __device__ __forceinline__ void bvh_leaf_pair(const DevScene<R>& sc, BvhQuery<R>
         const r4* rec1 = rec + (two ? sc.bvh_leaf_stride : 0u);
         const r4 c0 = rec[0], v0 = rec[1], c1 = rec1[0], v1 = rec1[1];
         cand0 = bvh_leaf_eval<R>(sc, q, leaf, 0u, c0, v0, o, d, ud, time, tmin);
+        pool0 = (int)bits(v0.w);
         if (two) cand1 = bvh_leaf_eval<R>(sc, q, leaf, 1u, c1, v1, o, d, ud, time, tmin);
+        pool1 = (int)bits(v1.w);
     } else {
-        cand0 = bvh_leaf_entry<R>(sc, q, leaf, 0u, o, d, ud, time, tmin);
-        if (two) cand1 = bvh_leaf_entry<R>(sc, q, leaf, 1u, o, d, ud, time, tmin);
+        const r4* rec = sc.bvh_leaf + (size_t)sc.bvh_leaf_stride * (leaf >> 4);
+        const r4 c0 = rec[0], v0 = rec[1];
+        cand0 = bvh_leaf_eval<R>(sc, q, leaf, 0u, c0, v0, o, d, ud, time, tmin);
+        pool0 = (int)bits(v0.w);
+        if (two) {
+            const r4 c1 = rec[sc.bvh_leaf_stride], v1 = rec[sc.bvh_leaf_stride + 1u];
+            cand1 = bvh_leaf_eval<R>(sc, q, leaf, 1u, c1, v1, o, d, ud, time, tmin);
+            pool1 = (int)bits(v1.w);
+        }
     }
 }
 
 // Phase C — the f64 quadratic of a parked sphere candidate (same arithmetic as narrow_phase()).
 template <class R>
+__device__ __forceinline__ void bvh_candidate(const DevScene<R>& sc, BvhQuery<R>& q, uint32_t slot, int pool, V<R> o, V<R> d, R time,
+                                              R tmin);
+template <class R>
 __device__ __forceinline__ void bvh_candidate(const DevScene<R>& sc, BvhQuery<R>& q, uint32_t slot, V<R> o, V<R> d, R time,
                                               R tmin) {
+    bvh_candidate<R>(sc, q, slot, (int)bits(sc.bvh_leaf[(size_t)sc.bvh_leaf_stride * slot + 1].w), o, d, time, tmin);
+}
+template <class R>
+__device__ __forceinline__ void bvh_candidate(const DevScene<R>& sc, BvhQuery<R>& q, uint32_t slot, int pool, V<R> o, V<R> d, R time,
+                                              R tmin) {
     const d4 c2 = sc.bvh_sph64[2 * slot], v2 = sc.bvh_sph64[2 * slot + 1];
-    const int pool = (int)bits(sc.bvh_leaf[(size_t)sc.bvh_leaf_stride * slot + 1].w);
     const double dx = d.x, dy = d.y, dz = d.z, tm = time;
     const double qx = fm(v2.x, tm, c2.x - (double)o.x), qy = fm(v2.y, tm, c2.y - (double)o.y),
                  qz = fm(v2.z, tm, c2.z - (double)o.z);
@@ -1542,11 +1562,12 @@ void trace_kernel_bvh(const TraceArgs<R> A) {
             if (__ballot(parked) == 0ull) break; // nobody parked: every walking lane ran out of nodes
             RAYZ_PROF_L(2, __popcll(__ballot(parked)))
             uint32_t cand0 = 0, cand1 = 0;
+            int pool0 = 0, pool1 = 0;
             if (parked) { // phase L
                 const uint32_t leaf = q.cur & ~kBvhLeafFlag;
                 sphere_tests += leaf & 3u;
-                bvh_leaf_pair<R>(A.sc, q, leaf, o, d, ud, time, A.tmin, cand0, cand1);
-                bvh_pop<R, kBvhWg>(q, stack);
+                bvh_pop<R, kBvhWg>(q, stack); // first: its LDS read-ahead travels while the records are fetched and tested
+                bvh_leaf_pair<R>(A.sc, q, leaf, o, d, ud, time, A.tmin, cand0, cand1, pool0, pool1);
             }
             RAYZ_PROF_T(2)
             if (__ballot((cand0 | cand1) != 0u) != 0ull) { // phase C
@@ -1554,9 +1575,10 @@ void trace_kernel_bvh(const TraceArgs<R> A) {
                 // a lane's only candidate goes into the first pass whichever entry it came from: the second pass runs
                 // only when some lane has two (the nearest hit does not depend on the order)
                 const uint32_t c0 = cand0 != 0u ? cand0 : cand1, c1 = cand0 != 0u ? cand1 : 0u;
-                if (c0 != 0u) bvh_candidate<R>(A.sc, q, c0 - 1u, o, d, time, A.tmin);
+                const int p0 = cand0 != 0u ? pool0 : pool1;
+                if (c0 != 0u) bvh_candidate<R>(A.sc, q, c0 - 1u, p0, o, d, time, A.tmin);
                 if (__ballot(c1 != 0u) != 0ull) {
-                    if (c1 != 0u) bvh_candidate<R>(A.sc, q, c1 - 1u, o, d, time, A.tmin);
+                    if (c1 != 0u) bvh_candidate<R>(A.sc, q, c1 - 1u, pool1, o, d, time, A.tmin);
                 }
             }
             RAYZ_PROF_T(3)
