@@ -1406,8 +1406,8 @@ __device__ __forceinline__ void bvh_candidate(const DevScene<R>& sc, BvhQuery<R>
 #ifndef RAYZ_STAT_SPILL
 #define RAYZ_STAT_SPILL 0x7fffffffu // tests build with a small value to exercise the spill
 #endif
-constexpr int kBvhKeepActive = 24;   // rounds continue while at least this many lanes still walk
-constexpr int kBvhKeepStepping = 16; // phase N continues while at least this many lanes can take a box step
+constexpr int kBvhKeepActive = 20;   // rounds continue while at least this many lanes still walk
+constexpr int kBvhKeepStepping = 18; // phase N continues while at least this many lanes can take a box step
                                      // (defaults; TraceArgs::bvh_keep carries the values in use)
 
 // Waves per SIMD the register allocation aims at: 4 (128 VGPRs, nothing spilled).  At 5 (96 VGPRs) the kernel spills 54
