@@ -1539,11 +1539,13 @@ void trace_kernel_bvh(const TraceArgs<R> A) {
         for (;;) {
             if constexpr (sizeof(R) == 8) q.tb32 = round_up_f32(q.tbest); // (tbest moves in phases L and C and in the set-up
                                                                           //  above, never in N)
-            for (;;) { // phase N: lanes holding an inner node step; lanes holding a leaf wait
-                const bool can_step = q.cur < kBvhDone;
-                const int n_can = __popcll(__ballot(can_step));
-                if (n_can == 0) break;
-                if (n_can < keep_stepping && __ballot((int32_t)q.cur < 0) != 0ull) break;
+            // phase N: lanes holding an inner node step; lanes holding a leaf wait.  It goes on while at least keep_stepping
+            // lanes can step — or any, if nobody waits at a leaf (ONE wave-uniform flag, computed where the lane count is
+            // known: the loop has a single exit test)
+            bool can_step = q.cur < kBvhDone;
+            int n_can = __popcll(__ballot(can_step));
+            bool run = n_can >= keep_stepping || (n_can != 0 && __ballot((int32_t)q.cur < 0) == 0ull);
+            while (run) {
                 RAYZ_PROF_L(0, n_can)
 #ifdef RAYZ_BVH_PROFILE
                 px3[0] += __popcll(__ballot((int32_t)q.cur < 0));
@@ -1562,6 +1564,9 @@ void trace_kernel_bvh(const TraceArgs<R> A) {
                 }
 #endif
                 node_tests += 2u * (uint32_t)n_can;
+                can_step = q.cur < kBvhDone;
+                n_can = __popcll(__ballot(can_step));
+                run = n_can >= keep_stepping || (n_can != 0 && __ballot((int32_t)q.cur < 0) == 0ull);
             }
             RAYZ_PROF_T(1)
             const bool parked = (int32_t)q.cur < 0;
