@@ -82,9 +82,18 @@ int main() {
     }
     { // the tree the GPU walks (surface-area split): every hittable in exactly one leaf of <= 2, skip links consistent, depth
       // within the budget the LDS stacks are sized for — small pools, the 10k grid (sweep) and a pool above kSweepMax (bins)
-        for (int g : {2, 11, 50, 40}) {
-            rayz::Tracer rb = g == 40 ? rayz::triangleMesh(32, 60, &seed) : rayz::randomBouncing(32, -g, g, &seed);
-            const rayz::Tracer::Flat fr = rb.flatten();
+        for (int g : {2, 11, 50, 40, -1, -2}) {
+            rayz::Tracer rb = g == 40 ? rayz::triangleMesh(32, 60, &seed) : rayz::randomBouncing(32, g < 0 ? -2 : -g, g < 0 ? 2 : g, &seed);
+            rayz::Tracer::Flat fr = rb.flatten();
+            if (g < 0) { // degenerate pools: 5,000 coincident spheres (no split position is better than another: halved), and
+                         // 3,000 on a line with one far outlier (every SAH split is lopsided: the depth budget must hold)
+                fr.spheres.assign(g == -1 ? 5000 : 3000, fr.spheres[1]);
+                if (g == -2) {
+                    for (size_t i = 0; i < fr.spheres.size(); ++i) fr.spheres[i].center[0] = std::pow(1.01, (double)i);
+                    fr.spheres.back().center[0] = 1e15;
+                }
+                fr.triangles.clear();
+            }
             const rayz_bvh::FlatBvh tr = rayz_bvh::build(fr.spheres, fr.triangles, true, true);
             const size_t n = fr.spheres.size() + fr.triangles.size();
             std::vector<int> seen(n, 0);
