@@ -1545,6 +1545,10 @@ void trace_kernel_bvh(const TraceArgs<R> A) {
             bool can_step = q.cur < kBvhDone;
             int n_can = __popcll(__ballot(can_step));
             bool run = n_can >= keep_stepping || (n_can != 0 && __ballot((int32_t)q.cur < 0) == 0ull);
+            // (wave priorities: the rounds' dependent chains — box steps above leaf and root phases — ahead of the throughput
+            //  work of the shading pass and the refill, which other waves' issue slots serve as well late as early:
+            //  +0.9 % config 3, +1.7 % config 5, profiles/r03/bvh_step/setprio.log)
+            __builtin_amdgcn_s_setprio(3);
             while (run) {
                 RAYZ_PROF_L(0, n_can)
 #ifdef RAYZ_BVH_PROFILE
@@ -1568,6 +1572,7 @@ void trace_kernel_bvh(const TraceArgs<R> A) {
                 n_can = __popcll(__ballot(can_step));
                 run = n_can >= keep_stepping || (n_can != 0 && __ballot((int32_t)q.cur < 0) == 0ull);
             }
+            __builtin_amdgcn_s_setprio(2);
             RAYZ_PROF_T(1)
             const bool parked = (int32_t)q.cur < 0;
             if (__ballot(parked) == 0ull) break; // nobody parked: every walking lane ran out of nodes
@@ -1597,6 +1602,7 @@ void trace_kernel_bvh(const TraceArgs<R> A) {
             if (n_walking == 0) break;
             if (n_walking < keep_active && n_walking < n_alive) break; // finished lanes wait: go shade / refill them
         }
+        __builtin_amdgcn_s_setprio(0);
 
         // ---- shade lanes whose query is complete ----
         RAYZ_PROF_T(1)
