@@ -1,6 +1,9 @@
-// bvh_build.hpp — host build of the reference's BVH, flattened for stackless GPU traversal.
+// bvh_build.hpp — host builds of the BVH, flattened (pre-order + skip links): the REFERENCE's tree, node for node (what
+// rayz_hip_scene_bvh exports and tests check against the oracle's own build), and the tree the GPU walks — the same
+// hittables and boxes, organised for fewer box tests (oversized hittables kept out, surface-area split: build()'s flags;
+// the nearest hit does not depend on the tree).
 //
-// The tree is the one `BVH.build` makes (src/hit.zig:130-161 of jlucier/rayz): hittables in pool order
+// The reference's tree is the one `BVH.build` makes (src/hit.zig:130-161 of jlucier/rayz): hittables in pool order
 // (src/ecs.zig:43-51) with `Sphere.boundingBox` boxes (src/geom.zig:24-31: union of the boxes at time 0 and
 // 1), node box = union of its hittables' boxes, leaves of ≤ 2, otherwise a STABLE sort (std.mem.sort) of the
 // node's range by `bbox.low[axis]` on the box's longest axis (`amax` tie rule, src/vec.zig:150-156) and a

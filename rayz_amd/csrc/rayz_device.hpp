@@ -1019,7 +1019,8 @@ constexpr uint32_t kBvhWg = RAYZ_BVH_WG, kBvh2Wg = 256; // (the two-path kernel 
 // LDS a BVH workgroup may ask for: hipFuncSetAttribute(MaxDynamicSharedMemorySize) refuses requests near the CU's 160 KB
 // (151,552 B accepted, 155,648 B refused on this stack), so the top of the tree is sized for 150 KB in all
 constexpr size_t kBvhLdsBudget = 150 * 1024;
-constexpr int kBvhStackDepth = 28;            // ≥ tree depth: median split gives ceil(log2(n / 2)) + 1 (n ≤ 2^27)
+constexpr int kBvhStackDepth = 32;            // ≥ tree depth: the halving tree's ceil(log2(n / 2)) + 1 (n ≤ 2^27) + the SAH build's
+                                              // 4 extra levels (bvh_build.hpp); (32 + 3) rows of 4 KB still fit kBvhLdsBudget
 constexpr uint32_t kBvhDone = 0x7fffffffu;     // cursor: nothing left to visit (positive: not a leaf reference)
 constexpr uint32_t kBvhLeafFlag = 0x80000000u; // child reference / stack entry is a leaf descriptor, not an inner index
 
@@ -1099,7 +1100,7 @@ template <class R> struct BvhQuery {
 constexpr double kBoxPadUlps = 16.0;
 // a tree gets 32-byte records of 16-bit plane indices instead of 64-byte records of f32 planes when it has more than this
 // many times the inner nodes the LDS top would hold as f32 planes (DevScene::bvh_nodes; measured in profiles/r03/lds_top)
-constexpr size_t kQuantizeAboveTops = 8;
+constexpr size_t kQuantizeAboveTops = 12;
 __device__ __forceinline__ float round_up_f32(float v) { return v; }
 __device__ __forceinline__ float round_up_f32(double v) { return __double2float_ru(v); }
 __device__ __forceinline__ float round_down_f32(float v) { return v; }
