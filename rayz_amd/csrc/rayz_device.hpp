@@ -227,12 +227,12 @@ template <class R> __device__ __forceinline__ uint32_t checker_parity(V<R> p, R 
     return s & 1u;
 }
 template <class R>
-__device__ __forceinline__ V<R> texture_value(const DevScene<R>& sc, uint32_t idx, V<R> p) { // src/material.zig:19-51
+__device__ __forceinline__ V<R> texture_value(const typename VecOf<R>::type* tex, uint32_t idx, V<R> p) { // src/material.zig:19-51
     typedef typename VecOf<R>::type r4;
     for (int depth = 0; depth < kMaxTextureDepth; ++depth) { // rayz_hip_scene_create refuses deeper chains and cycles
-        const r4 h = sc.tex[2 * idx];
+        const r4 h = tex[2 * idx];
         if (bits(h.x) == 1u) { // RAYZ_TEX_SOLID
-            const r4 c = sc.tex[2 * idx + 1];
+            const r4 c = tex[2 * idx + 1];
             return {c.x, c.y, c.z};
         }
         idx = checker_parity<R>(p, h.w) == 0u ? bits(h.y) : bits(h.z);
@@ -747,6 +747,12 @@ template <class R>
 __device__ __forceinline__ bool shade(const DevScene<R>& sc, Pcg32& g, V<R>& o, V<R>& d, V<R> ud, R time, R tbest,
                                       int ibest, V<R>& thr, V<R>& acc) {
     typedef typename VecOf<R>::type r4;
+    // The pass's three table pointers, read ONCE here: left to itself the compiler re-loads each kernel argument where it is
+    // used (scalar registers are short), a scalar load + wait in front of every dependent table fetch of the pass.
+    const r4* pool_p = sc.sph_pool;
+    const r4* mat_p = sc.mat;
+    const r4* tex_p = sc.tex;
+    asm volatile("" : "+s"(pool_p), "+s"(mat_p), "+s"(tex_p));
     if (ibest < 0) {
         const V<R> col = background<R>(ud);
         acc.x = acc.x + thr.x * col.x;
@@ -758,7 +764,7 @@ __device__ __forceinline__ bool shade(const DevScene<R>& sc, Pcg32& g, V<R>& o, 
     V<R> pt, nrm;
     uint32_t mat_idx;
     if ((uint32_t)ibest < sc.n_spheres) {
-        const r4 q = sc.sph_pool[2 * ibest], w4 = sc.sph_pool[2 * ibest + 1];
+        const r4 q = pool_p[2 * ibest], w4 = pool_p[2 * ibest + 1];
         sphere_hit_record<R>(q, w4, o, d, time, tbest, pt, nrm);
         mat_idx = bits(w4.w);
     } else {
@@ -770,11 +776,11 @@ __device__ __forceinline__ bool shade(const DevScene<R>& sc, Pcg32& g, V<R>& o, 
     }
     const bool front = face_forward<R>(d, nrm);
 
-    const r4 m = sc.mat[mat_idx];
+    const r4 m = mat_p[mat_idx];
     const uint32_t kind = bits(m.x) & 0xffu, method = (bits(m.x) >> 8) & 0xffu, texture = bits(m.y);
     V<R> nd;
     if (!scatter_dir<R>(kind, method, m.z, m.w, g, d, ud, pt, nrm, front, nd)) return false;
-    const V<R> att = kind == 2u ? V<R>{R(1), R(1), R(1)} : texture_value<R>(sc, texture, pt);
+    const V<R> att = kind == 2u ? V<R>{R(1), R(1), R(1)} : texture_value<R>(tex_p, texture, pt);
     thr = {thr.x * att.x, thr.y * att.y, thr.z * att.z};
     o = pt;
     d = nd;
