@@ -353,7 +353,8 @@ def run(args, json_fd):
                 rec["roofline"]["note"] = ("filter flops (f32 box / reject tests) only; the f64 narrow phase, hit records and shading are "
                                            "not counted, so no utilisation fraction is claimed for the f64 fidelity mode")
             elif bvh:
-                rec["roofline"]["note"] = (f"per-lane tree walk, vector-issue-bound at ~31 of 64 lanes per instruction (profiles/): priced "
+                rec["roofline"]["note"] = (f"per-lane tree walk at ~31 of 64 lanes per instruction, bound by its dependent chains, the vector-memory address pipe and the "
+                                           f"issue slots together rather than by flops (DESIGN.md 6, profiles/): priced "
                                            f"against the vector peak with {FLOP_PER_BOX_TEST} flop per box test + {FLOP_PER_TEST_MOVING} per leaf test")
             if bvh:
                 rec["node_tests_per_segment"] = st.node_tests / max(st.segments, 1)
