@@ -122,6 +122,7 @@ template <class R> struct TraceArgs {
     uint32_t total_items;
     uint32_t bvh_keep;       // BVH kernel: keep_active | keep_stepping << 8 (see trace_kernel_bvh)
     uint32_t bvh_top_words;   // BVH kernel: u32s of LDS taken by the copy of the tree's top (the per-lane stacks follow)
+    uint32_t bvh_big_words;   // BVH kernel: where (in u32s of LDS) the oversized hittables' records are kept, after the stacks
     uint32_t queue_grab;     // work items a wave reserves per atomic on the queue head (kQueueGrab; scheduling only)
 };
 
@@ -1025,6 +1026,12 @@ constexpr uint32_t kBvhWg = RAYZ_BVH_WG, kBvh2Wg = 256; // (the two-path kernel 
 // LDS a BVH workgroup may ask for: hipFuncSetAttribute(MaxDynamicSharedMemorySize) refuses requests near the CU's 160 KB
 // (151,552 B accepted, 155,648 B refused on this stack), so the top of the tree is sized for 150 KB in all
 constexpr size_t kBvhLdsBudget = 150 * 1024;
+// .. of which this much, after the stacks, holds the oversized hittables' records (the filter record's three words in R and
+// the f64 sphere record, per entry; at most 4 descriptors of 2): the per-segment set-up reads them from LDS, not through
+// two dependent trips to the L2
+constexpr uint32_t kBvhBigEntries = 8;
+template <class R> constexpr uint32_t bvh_big_entry_bytes() { return 2u * (uint32_t)sizeof(d4) + 4u * (uint32_t)sizeof(typename VecOf<R>::type); } // (f64 record first: 32-byte aligned)
+constexpr size_t kBvhBigLdsBytes = kBvhBigEntries * (2 * 32 + 4 * 32);
 constexpr int kBvhStackDepth = 32;            // ≥ tree depth: the halving tree's ceil(log2(n / 2)) + 1 (n ≤ 2^27) + the SAH build's
                                               // 4 extra levels (bvh_build.hpp); (32 + 3) rows of 4 KB still fit kBvhLdsBudget
 constexpr uint32_t kBvhDone = 0x7fffffffu;     // cursor: nothing left to visit (positive: not a leaf reference)
@@ -1323,11 +1330,12 @@ __device__ __forceinline__ bool leaf_reject_test(const RayBasis<float>& b, float
 // (a sphere's pool index rides in its record's last word, v.w: phase C takes it from there — see bvh_leaf_pair)
 template <class R>
 __device__ __forceinline__ uint32_t bvh_leaf_eval(const DevScene<R>& sc, BvhQuery<R>& q, uint32_t leaf, uint32_t k, typename VecOf<R>::type c,
-                                                  typename VecOf<R>::type v, V<R> o, V<R> d, V<R> ud, R time, R tmin) {
+                                                  typename VecOf<R>::type v, V<R> o, V<R> d, V<R> ud, R time, R tmin,
+                                                  const typename VecOf<R>::type* third_word = nullptr) {
     typedef typename VecOf<R>::type r4;
     const uint32_t slot = (leaf >> 4) + k;
     if ((leaf >> (2u + k)) & 1u) { // triangle
-        const r4 e2 = sc.bvh_leaf[(size_t)sc.bvh_leaf_stride * slot + 2];
+        const r4 e2 = third_word ? *third_word : sc.bvh_leaf[(size_t)sc.bvh_leaf_stride * slot + 2];
         const V<R> v0{c.x, c.y, c.z}, e1{v.x, v.y, v.z}, ee2{e2.x, e2.y, e2.z};
         tri_accept<R>(tri_filter<R>(v0, e1, ee2, o, d), v0, e1, ee2, o, d, tmin, (int)bits(c.w), q.tbest, q.ibest);
         return 0u;
@@ -1387,9 +1395,14 @@ __device__ __forceinline__ void bvh_candidate(const DevScene<R>& sc, BvhQuery<R>
     bvh_candidate<R>(sc, q, slot, (int)bits(sc.bvh_leaf[(size_t)sc.bvh_leaf_stride * slot + 1].w), o, d, time, tmin);
 }
 template <class R>
+__device__ __forceinline__ void bvh_candidate_eval(BvhQuery<R>& q, const d4 c2, const d4 v2, int pool, V<R> o, V<R> d, R time, R tmin);
+template <class R>
 __device__ __forceinline__ void bvh_candidate(const DevScene<R>& sc, BvhQuery<R>& q, uint32_t slot, int pool, V<R> o, V<R> d, R time,
                                               R tmin) {
-    const d4 c2 = sc.bvh_sph64[2 * slot], v2 = sc.bvh_sph64[2 * slot + 1];
+    bvh_candidate_eval<R>(q, sc.bvh_sph64[2 * slot], sc.bvh_sph64[2 * slot + 1], pool, o, d, time, tmin);
+}
+template <class R>
+__device__ __forceinline__ void bvh_candidate_eval(BvhQuery<R>& q, const d4 c2, const d4 v2, int pool, V<R> o, V<R> d, R time, R tmin) {
     const double dx = d.x, dy = d.y, dz = d.z, tm = time;
     const double qx = fm(v2.x, tm, c2.x - (double)o.x), qy = fm(v2.y, tm, c2.y - (double)o.y),
                  qz = fm(v2.z, tm, c2.z - (double)o.z);
@@ -1468,6 +1481,22 @@ void trace_kernel_bvh(const TraceArgs<R> A) {
     for (uint32_t k = threadIdx.x; k < A.sc.bvh_top / 16u; k += kBvhWg) top[k] = A.sc.bvh_nodes[k];
     const f4* nodes_base = scalar_base(A.sc.bvh_nodes);
     stack[0] = kBvhDone; // the sentinel under every lane's stack
+    // the oversized hittables' records, entry e = 2·(descriptor) + (entry of it): {filter record: 3 words in R, f64 sphere: 2}
+    unsigned char* big_lds = (unsigned char*)(lds_words + A.bvh_big_words);
+    if (threadIdx.x < 2u * A.sc.bvh_n_big_leaves) {
+        const uint32_t desc = A.sc.bvh_big[threadIdx.x >> 1], j = threadIdx.x & 1u;
+        if (j < (desc & 3u)) {
+            const uint32_t slot = (desc >> 4) + j;
+            d4* dst64 = (d4*)(big_lds + threadIdx.x * bvh_big_entry_bytes<R>());
+            dst64[0] = A.sc.bvh_sph64[2 * slot];
+            dst64[1] = A.sc.bvh_sph64[2 * slot + 1];
+            r4* dst = (r4*)(dst64 + 2);
+            const r4* rec = A.sc.bvh_leaf + (size_t)A.sc.bvh_leaf_stride * slot;
+            dst[0] = rec[0];
+            dst[1] = rec[1];
+            dst[2] = A.sc.bvh_leaf_stride > 2u ? rec[2] : rec[1];
+        }
+    }
     __syncthreads();
     R time = 0;
     uint32_t item = 0, px = 0, py = 0, s_cur = 0, s_end = 0, seg = 0, nseg = 0, sphere_tests = 0;
@@ -1531,10 +1560,13 @@ void trace_kernel_bvh(const TraceArgs<R> A) {
                 for (uint32_t k = 0; k < A.sc.bvh_n_big_leaves; ++k) { // wave-uniform trip count
                     const uint32_t desc = A.sc.bvh_big[k];
                     sphere_tests += desc & 3u;
-                    const uint32_t c0 = bvh_leaf_entry<R>(A.sc, q, desc, 0u, o, d, ud, time, A.tmin);
-                    const uint32_t c1 = (desc & 3u) > 1u ? bvh_leaf_entry<R>(A.sc, q, desc, 1u, o, d, ud, time, A.tmin) : 0u;
-                    if (c0 != 0u) bvh_candidate<R>(A.sc, q, c0 - 1u, o, d, time, A.tmin);
-                    if (c1 != 0u) bvh_candidate<R>(A.sc, q, c1 - 1u, o, d, time, A.tmin);
+                    for (uint32_t j = 0; j < (desc & 3u); ++j) { // (from the LDS copy: the same address in every lane)
+                        const d4* rec64 = (const d4*)(big_lds + (2u * k + j) * bvh_big_entry_bytes<R>());
+                        const r4* rec = (const r4*)(rec64 + 2);
+                        const r4 c = rec[0], v = rec[1], w = rec[2];
+                        if (bvh_leaf_eval<R>(A.sc, q, desc, j, c, v, o, d, ud, time, A.tmin, &w) != 0u)
+                            bvh_candidate_eval<R>(q, rec64[0], rec64[1], (int)bits(v.w), o, d, time, A.tmin);
+                    }
                 }
             }
         }

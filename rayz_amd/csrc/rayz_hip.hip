@@ -465,7 +465,7 @@ template <class R> int upload_bvh_body(RayzScene* s, SceneBuffers<R>& b) {
     {
         // top-of-tree records kept in LDS: as many as fit beside the stacks of the one-path kernel's workgroup (the two-path
         // kernel, with its smaller workgroups, keeps a prefix of them); RAYZ_DEBUG_BVH_TOP lowers the cap
-        const size_t stacks = ((size_t)t.depth + 3) * kBvhWg * sizeof(uint32_t);
+        const size_t stacks = ((size_t)t.depth + 3) * kBvhWg * sizeof(uint32_t) + (t.big.empty() ? 0 : kBvhBigLdsBytes); // (+ the oversized hittables' records)
         const size_t lds_for_top = stacks < kBvhLdsBudget ? kBvhLdsBudget - stacks : 0;
         // WHICH record format (DevScene::bvh_nodes): 16-bit plane indices halve the bytes a step fetches and double the
         // records the LDS top holds, for 12 conversions per step — worth it only when most steps fetch from global memory,
@@ -867,8 +867,9 @@ int render_impl(RayzScene* s, const DeviceCtx& ctx, SceneBuffers<R>& b, const Ra
     if (two_paths) top_records = std::min<uint32_t>(top_records, b.quantized ? 512u : 256u);
     const size_t bvh_top_bytes = (size_t)top_records * (b.quantized ? 32 : 64);
     // (+ RAYZ_DEBUG_LDS_PAD unused bytes: an occupancy experiment — fewer workgroups per CU, the same code)
-    const size_t bvh_lds = bvh_top_bytes + bvh_stack_bytes + (use_bvh ? (size_t)tuning(RAYZ_DEBUG_LDS_PAD, 0) : 0);
+    const size_t bvh_lds = bvh_top_bytes + bvh_stack_bytes + (use_bvh ? (b.n_big_leaves ? kBvhBigLdsBytes : 0) + (size_t)tuning(RAYZ_DEBUG_LDS_PAD, 0) : 0);
     A.bvh_top_words = (uint32_t)(bvh_top_bytes / sizeof(uint32_t));
+    A.bvh_big_words = (uint32_t)((bvh_top_bytes + bvh_stack_bytes) / sizeof(uint32_t));
     A.sc.bvh_top = (uint32_t)bvh_top_bytes; // the walk compares byte offsets
     typedef void (*Kernel)(const TraceArgs<R>);
     Kernel kernel = trace_kernel<R, 1>;
