@@ -1128,7 +1128,9 @@ constexpr float kInvCap = 0x1p64f;
 __device__ __forceinline__ float capped_inverse(float dk) { // (one v_med3_f32 behind the division)
     return __builtin_amdgcn_fmed3f(1.0f / dk, -kInvCap, kInvCap);
 }
-template <class R, class SC>
+// (kGrid = false — a kernel whose records hold f32 planes: the grid is origin 0, cell 1, so qa = inv and qb = noi exactly;
+//  the six operations and the grid's kernel arguments are skipped)
+template <class R, bool kGrid = true, class SC>
 __device__ __forceinline__ void bvh_begin(BvhQuery<R>& q, const SC& sc, V<R> o, V<R> d, V<R> ud, uint32_t n_inner) {
     q.lb.make(ud, o);
     V<float> inv;
@@ -1142,8 +1144,13 @@ __device__ __forceinline__ void bvh_begin(BvhQuery<R>& q, const SC& sc, V<R> o, 
     // −o·inv with the origin at full precision, rounded once; then the grid folded in: a plane with index i lies at
     // glo + i·cell, so its distance (glo + i·cell − o)·inv is fm(i, cell·inv, fm(glo, inv, −o·inv))
     const V<float> noi{(float)(-(o.x * (R)inv.x)), (float)(-(o.y * (R)inv.y)), (float)(-(o.z * (R)inv.z))};
-    q.qa = {sc.bvh_cell[0] * inv.x, sc.bvh_cell[1] * inv.y, sc.bvh_cell[2] * inv.z};
-    q.qb = {fm(sc.bvh_glo[0], inv.x, noi.x), fm(sc.bvh_glo[1], inv.y, noi.y), fm(sc.bvh_glo[2], inv.z, noi.z)};
+    if constexpr (kGrid) {
+        q.qa = {sc.bvh_cell[0] * inv.x, sc.bvh_cell[1] * inv.y, sc.bvh_cell[2] * inv.z};
+        q.qb = {fm(sc.bvh_glo[0], inv.x, noi.x), fm(sc.bvh_glo[1], inv.y, noi.y), fm(sc.bvh_glo[2], inv.z, noi.z)};
+    } else {
+        q.qa = inv;
+        q.qb = noi;
+    }
     const double ddx = d.x, ddy = d.y, ddz = d.z;
     q.inv_a2 = 1.0 / fm(ddz, ddz, fm(ddy, ddy, ddx * ddx));
     q.tbest = (R)__builtin_inff();
@@ -1552,7 +1559,7 @@ void trace_kernel_bvh(const TraceArgs<R> A) {
         //      for the per-segment set-up (unit direction, slab constants) ----
         if (fresh) {
             ud = unit(d);
-            bvh_begin<R>(q, A.sc, o, d, ud, n_nodes);
+            bvh_begin<R, QUANT>(q, A.sc, o, d, ud, n_nodes);
         }
         // .. then the oversized hittables kept out of the tree: the walk starts with their tbest and culls behind it
         if (A.sc.bvh_n_big_leaves != 0u && __ballot(fresh) != 0ull) {
@@ -1843,7 +1850,7 @@ template <class R, bool QUANT> __global__ __launch_bounds__(256, RAYZ_BVH2_WAVES
             // out of the tree: the walk starts with their tbest
             if (fresh) {
                 pud = unit(pd);
-                bvh_begin<R>(pq, A.sc, po, pd, pud, n_nodes);
+                bvh_begin<R, QUANT>(pq, A.sc, po, pd, pud, n_nodes);
             }
             if (A.sc.bvh_n_big_leaves != 0u && __ballot(fresh) != 0ull) {
                 if (fresh) {
