@@ -119,6 +119,35 @@ int main() {
             bad |= !ok;
         }
     }
+    { // the 16-bit plane indices of the walked tree's node records (bvh_build.hpp: PlaneGrid): every quantised box contains
+      // the padded box it stands for, over grids of very different position and extent
+        uint64_t st = 88172645463325252ull;
+        auto rnd = [&]() { st ^= st << 13, st ^= st >> 7, st ^= st << 17; return (double)(st >> 11) * (1.0 / 9007199254740992.0); };
+        size_t checked = 0, broken = 0;
+        for (int g = 0; g < 200; ++g) {
+            const double scale = std::pow(10.0, -3.0 + 9.0 * rnd()), shift = (rnd() - 0.5) * scale * std::pow(10.0, 3.0 * rnd());
+            double lo[3], hi[3];
+            for (int k = 0; k < 3; ++k) lo[k] = shift - scale * rnd(), hi[k] = shift + scale * rnd();
+            const double pad = 1e-6 * scale * rnd();
+            const rayz_bvh::PlaneGrid grid = rayz_bvh::PlaneGrid::over(lo, hi, 2.0 * pad);
+            for (int b = 0; b < 500; ++b) {
+                rayz_bvh::Box bx;
+                for (int k = 0; k < 3; ++k) {
+                    const double a = lo[k] + (hi[k] - lo[k]) * rnd(), c = lo[k] + (hi[k] - lo[k]) * rnd();
+                    bx.lo[k] = std::fmin(a, c), bx.hi[k] = b % 7 == 0 ? bx.lo[k] : std::fmax(a, c); // (flat boxes too)
+                }
+                uint32_t w[3];
+                grid.quantize(bx, pad, w);
+                for (int k = 0; k < 3; ++k) {
+                    const uint32_t il = w[k] & 0xffffu, ih = w[k] >> 16;
+                    ++checked;
+                    broken += !(grid.plane(k, il) <= bx.lo[k] - pad && grid.plane(k, ih) >= bx.hi[k] + pad && il <= ih);
+                }
+            }
+        }
+        std::printf("plane grid: %zu quantised planes pairs checked, %zu not conservative\n", checked, broken);
+        bad |= broken != 0;
+    }
     FILE* f = std::fopen("/dev/null", "w");
     t1.img.writePPM(f);
     std::fclose(f);
