@@ -159,7 +159,9 @@ typedef struct RayzRenderParams {
 typedef struct RayzRenderStats {
     uint64_t primary_rays; /* rows_in_shard * width * samples_per_px */
     uint64_t segments;     /* findHit calls: one per ray segment, src/renderer.zig:107 */
-    uint64_t sphere_tests; /* primitive tests: Sphere.hitInner evaluations (src/geom.zig:38-66) + triangle tests */
+    uint64_t sphere_tests; /* primitive tests: Sphere.hitInner evaluations (src/geom.zig:38-66) + triangle tests.  BVH: counted by
+                              the kernel (leaf entries examined).  Flat list: DERIVED, segments x hittables — every segment scans
+                              the whole list, so the kernel counts segments only */
     uint64_t node_tests;   /* AABB.hit evaluations (BVH traversal only), src/hit.zig:70-98 */
     double kernel_ms;      /* HIP-event time of the trace kernel(s) of the last render on this scene */
 } RayzRenderStats;

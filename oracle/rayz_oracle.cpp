@@ -1241,7 +1241,21 @@ static int render(const RayzSceneDesc* sd, const RayzCameraDesc* cd, const RayzR
         const u64 spp = p.samples_per_px;
         const bool uniform = p.chunk_spp != 0 || (u64)p.width * p.height < (1ull << 19) || spp < 64;
         const u64 c = p.chunk_spp ? p.chunk_spp : 16;
-        if ((uniform ? (spp + c - 1) / c : spp / 256 + 8) >= (1ull << 20)) return RAYZ_ERR_BAD_ARG;
+        u64 n = (spp + c - 1) / c;
+        if (!uniform) { // the automatic schedule's length, exactly: full chunks of C while 2C remain, then the halving tail
+            u64 C = 1;
+            while (C <= spp / 4 && C < 256) C *= 2;
+            n = 0;
+            u64 rem = spp;
+            if (rem >= 2 * C) n = (rem - 2 * C) / C + 1, rem -= n * C;
+            while (rem > 16) {
+                u64 h = 1;
+                while (h <= rem / 4) h *= 2;
+                rem -= h < 16 ? 16 : h, ++n;
+            }
+            n += rem ? 1 : 0;
+        }
+        if (n >= (1ull << 20)) return RAYZ_ERR_BAD_ARG;
     }
     SceneB<R> sc = buildScene<R>(*sd, originBound(*sd, cd));
     if (useBvh(*pp, sd->n_spheres + sd->n_triangles)) buildBvh<R>(*sd, sc, originBound(*sd, cd));

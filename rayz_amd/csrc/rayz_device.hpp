@@ -1022,9 +1022,14 @@ template <class R, int NR> __global__ __launch_bounds__(256, (flat_waves<R, NR>(
 #ifndef RAYZ_BVH_WG
 #define RAYZ_BVH_WG 1024
 #endif
-constexpr uint32_t kBvhWg = RAYZ_BVH_WG, kBvh2Wg = 256; // (the two-path kernel needs 168 VGPRs: 256-thread workgroups, 3 per CU)
+constexpr uint32_t kBvhWg = RAYZ_BVH_WG;
+#ifdef RAYZ_EXPERIMENTS
+constexpr uint32_t kBvh2Wg = 256; // (the retired two-path kernel needs 168 VGPRs: 256-thread workgroups, 3 per CU)
+#endif
 // LDS a BVH workgroup may ask for: hipFuncSetAttribute(MaxDynamicSharedMemorySize) refuses requests near the CU's 160 KB
-// (151,552 B accepted, 155,648 B refused on this stack), so the top of the tree is sized for 150 KB in all
+// (151,552 B accepted, 155,648 B refused when probed in round 2; rounds 3-4 ran every BVH render with 153,600 B), so the top of
+// the tree is sized for 150 KB in all.  A stack that refuses that is not fatal: render_impl retries with a shorter prefix
+// of the top, 8 KB at a time (tests/test_bvh.py exercises the retry through RAYZ_DEBUG_LDS_PAD).
 constexpr size_t kBvhLdsBudget = 150 * 1024;
 // .. of which this much, after the stacks, holds the oversized hittables' records (the filter record's three words in R and
 // the f64 sphere record, per entry; at most 4 descriptors of 2): the per-segment set-up reads them from LDS, not through
@@ -1590,7 +1595,9 @@ void trace_kernel_bvh(const TraceArgs<R> A) {
             // known: the loop has a single exit test)
             bool can_step = q.cur < kBvhDone;
             int n_can = __popcll(__ballot(can_step));
-            bool run = n_can >= keep_stepping || (n_can != 0 && __ballot((int32_t)q.cur < 0) == 0ull);
+            // (n_can != 0 first: with nobody able to step the loop must end whatever the threshold is — a threshold of 0 would
+            //  otherwise spin for ever with no lane stepping)
+            bool run = n_can != 0 && (n_can >= keep_stepping || __ballot((int32_t)q.cur < 0) == 0ull);
             // (wave priorities: the rounds' dependent chains — box steps above leaf and root phases — ahead of the throughput
             //  work of the shading pass and the refill, which other waves' issue slots serve as well late as early:
             //  +0.9 % config 3, +1.7 % config 5, profiles/r03/bvh_step/setprio.log)
@@ -1616,7 +1623,7 @@ void trace_kernel_bvh(const TraceArgs<R> A) {
                 node_tests += 2u * (uint32_t)n_can;
                 can_step = q.cur < kBvhDone;
                 n_can = __popcll(__ballot(can_step));
-                run = n_can >= keep_stepping || (n_can != 0 && __ballot((int32_t)q.cur < 0) == 0ull);
+                run = n_can != 0 && (n_can >= keep_stepping || __ballot((int32_t)q.cur < 0) == 0ull);
             }
             __builtin_amdgcn_s_setprio(2);
             RAYZ_PROF_T(1)
@@ -1689,7 +1696,10 @@ void trace_kernel_bvh(const TraceArgs<R> A) {
     }
 }
 
+#ifdef RAYZ_EXPERIMENTS
 // ---- persistent trace kernel, BVH traversal, TWO paths per lane -------------------------------------------------
+// RETIRED EXPERIMENT (round 3: bit-identical, 19 % slower — DESIGN.md §6): compiled only with -DRAYZ_EXPERIMENTS (tools/bvh2_bench.py
+// builds its own library with it); the product library does not contain it.
 // trace_kernel_bvh above issues its box steps for ~39 of 64 lanes (profiles/r02): a lane whose walk is complete sits idle
 // until enough lanes have finished to make the long shading pass worth running (≈14 lanes on average), and the pass
 // itself then runs for the ~45 lanes that are ready.  Here every lane owns TWO path contexts.  One is held by the lane's
@@ -1975,6 +1985,7 @@ template <class R, bool QUANT> __global__ __launch_bounds__(256, RAYZ_BVH2_WAVES
         atomicAdd(&A.counters[3], t2);
     }
 }
+#endif // RAYZ_EXPERIMENTS
 
 // ---- pixel = (Σ_chunks partial) · (1/spp), chunk order: src/renderer.zig:94-95 ---------------------
 template <class R>

@@ -205,7 +205,17 @@ uint64_t chunk_count(const RayzRenderParams* p) {
         const uint64_t c = p->chunk_spp ? p->chunk_spp : 16u;
         return (spp + c - 1) / c;
     }
-    return spp / 256 + 8; // chunks of 256 (or fewer, larger-than-needed bound for spp < 512) + the halving tail
+    // the automatic schedule, counted exactly by chunk_schedule's own rule (the full chunks in closed form, the halving
+    // tail by its ≤ 10 steps): `spp / 256 + 8` undercounted tails of 256 .. 511 samples by one (spp = 497: 10 chunks)
+    auto pow2floor = [](uint64_t v) {
+        uint64_t r = 1;
+        while (r <= v / 2) r *= 2;
+        return r;
+    };
+    const uint64_t C = std::min<uint64_t>(256, pow2floor(spp / 2));
+    uint64_t n = spp >= 2 * C ? (spp - 2 * C) / C + 1 : 0, rem = spp - n * C;
+    while (rem > 16) rem -= std::max<uint64_t>(16, pow2floor(rem / 2)), ++n;
+    return n + (rem ? 1 : 0);
 }
 
 double norm3(const double* v) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
@@ -846,14 +856,19 @@ int render_impl(RayzScene* s, const DeviceCtx& ctx, SceneBuffers<R>& b, const Ra
     A.tiled_pixels = p->width % 8 == 0 ? (uint32_t)((uint64_t)(rows / 8 * 8) * p->width) : 0u; // whole 8x8 tiles of the local rows (place_item)
     A.total_items = (uint32_t)items64;
     A.queue_grab = (uint32_t)std::max(1ll, tuning(RAYZ_DEBUG_QUEUE_GRAB, kQueueGrab));
-    // Which walk: one path per lane (trace_kernel_bvh).  The two-paths-per-lane form (trace_kernel_bvh2, f32 only) is kept
-    // behind RAYZ_DEBUG_BVH_KERNEL = 2: same image, but its 168 VGPRs cost a wave per SIMD and it is slower.
+    // Which walk: one path per lane (trace_kernel_bvh).  The two-paths-per-lane form (trace_kernel_bvh2, f32 only: same image,
+    // 19 % slower) is a retired experiment: only a -DRAYZ_EXPERIMENTS build contains it (RAYZ_DEBUG_BVH_KERNEL = 2).
+#ifdef RAYZ_EXPERIMENTS
     const bool two_paths = use_bvh && sizeof(R) == 4 && tuning(RAYZ_DEBUG_BVH_KERNEL, 1) == 2;
-    // scheduling thresholds of the BVH kernels (no effect on results)
+#else
+    const bool two_paths = false;
+#endif
+    // scheduling thresholds of the BVH kernel (no effect on results; rayz_hip_debug_set refuses values outside 1 .. 64 lanes)
+    A.bvh_keep = (uint32_t)tuning(RAYZ_DEBUG_BVH_KEEP, kBvhKeepActive | (kBvhKeepStepping << 8));
+#ifdef RAYZ_EXPERIMENTS
     if (two_paths)
         A.bvh_keep = (uint32_t)tuning(RAYZ_DEBUG_BVH2_KEEP, kBvh2Service | (kBvh2Blocked << 8) | (kBvh2Swap << 16) | (kBvhKeepStepping << 24));
-    else
-        A.bvh_keep = (uint32_t)tuning(RAYZ_DEBUG_BVH_KEEP, kBvhKeepActive | (kBvhKeepStepping << 8));
+#endif
 
     const int block = (use_bvh && !two_paths) ? (int)kBvhWg : 256;
     int blocks_per_cu = 0;
@@ -865,22 +880,40 @@ int render_impl(RayzScene* s, const DeviceCtx& ctx, SceneBuffers<R>& b, const Ra
     // a kernel whose workgroup has less LDS to spare (two paths per lane: three 256-thread workgroups per CU) keeps a prefix
     uint32_t top_records = use_bvh ? b.bvh_top : 0u;
     if (two_paths) top_records = std::min<uint32_t>(top_records, b.quantized ? 512u : 256u);
-    const size_t bvh_top_bytes = (size_t)top_records * (b.quantized ? 32 : 64);
-    // (+ RAYZ_DEBUG_LDS_PAD unused bytes: an occupancy experiment — fewer workgroups per CU, the same code)
-    const size_t bvh_lds = bvh_top_bytes + bvh_stack_bytes + (use_bvh ? (b.n_big_leaves ? kBvhBigLdsBytes : 0) + (size_t)tuning(RAYZ_DEBUG_LDS_PAD, 0) : 0);
+    typedef void (*Kernel)(const TraceArgs<R>);
+    Kernel kernel = trace_kernel<R, 1>;
+    if (use_bvh) kernel = b.quantized ? trace_kernel_bvh<R, true> : trace_kernel_bvh<R, false>;
+#ifdef RAYZ_EXPERIMENTS
+    if (two_paths) {
+        if constexpr (sizeof(R) == 4) kernel = b.quantized ? trace_kernel_bvh2<float, true> : trace_kernel_bvh2<float, false>;
+    }
+#endif
+    // The LDS request: top | stacks | oversized hittables' records (+ RAYZ_DEBUG_LDS_PAD unused bytes: an occupancy experiment —
+    // fewer workgroups per CU, the same code).  The top was sized for kBvhLdsBudget, which this driver stack accepts; should a
+    // stack refuse the request (hipFuncSetAttribute fails, or the occupancy query finds room for no workgroup), the launch keeps
+    // a SHORTER PREFIX of the top instead of failing every BVH render — the walk works with any prefix (records beyond it are
+    // read from global memory), only slower.
+    const size_t rec_bytes = b.quantized ? 32 : 64;
+    const size_t bvh_fixed = use_bvh ? bvh_stack_bytes + (b.n_big_leaves ? kBvhBigLdsBytes : 0) + (size_t)tuning(RAYZ_DEBUG_LDS_PAD, 0) : 0;
+    size_t bvh_top_bytes = 0, bvh_lds = 0;
+    for (;;) {
+        bvh_top_bytes = (size_t)top_records * rec_bytes;
+        bvh_lds = bvh_top_bytes + bvh_fixed;
+        hipError_t e = hipSuccess;
+        if (use_bvh && bvh_lds > 64 * 1024) // a workgroup that asks for more than 64 KB of LDS has to say so first
+            e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bvh_lds);
+        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kernel, block, use_bvh ? bvh_lds : 0);
+        if (e == hipSuccess && (blocks_per_cu >= 1 || !use_bvh)) break;
+        (void)hipGetLastError(); // (clear the sticky error of the refused request)
+        if (!use_bvh || top_records == 0)
+            return fail(RAYZ_ERR_HIP, "the trace kernel cannot be launched with %zu bytes of LDS: %s", bvh_lds,
+                        e == hipSuccess ? "no workgroup fits a CU" : hipGetErrorString(e));
+        const uint32_t step = (uint32_t)(8192 / rec_bytes); // give back 8 KB of the top per try
+        top_records = top_records > step ? top_records - step : 0u;
+    }
     A.bvh_top_words = (uint32_t)(bvh_top_bytes / sizeof(uint32_t));
     A.bvh_big_words = (uint32_t)((bvh_top_bytes + bvh_stack_bytes) / sizeof(uint32_t));
     A.sc.bvh_top = (uint32_t)bvh_top_bytes; // the walk compares byte offsets
-    typedef void (*Kernel)(const TraceArgs<R>);
-    Kernel kernel = trace_kernel<R, 1>;
-    if (two_paths) {
-        if constexpr (sizeof(R) == 4) kernel = b.quantized ? trace_kernel_bvh2<float, true> : trace_kernel_bvh2<float, false>;
-    } else if (use_bvh) {
-        kernel = b.quantized ? trace_kernel_bvh<R, true> : trace_kernel_bvh<R, false>;
-    }
-    if (use_bvh && bvh_lds > 64 * 1024) // a workgroup that asks for more than 64 KB of LDS has to say so first
-        HIP_TRY(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bvh_lds));
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kernel, block, use_bvh ? bvh_lds : 0));
     if (blocks_per_cu < 1) blocks_per_cu = 1;
     uint64_t grid = (uint64_t)ctx.num_cu * blocks_per_cu;
     // (a lane of the two-path kernel holds two items)
@@ -1345,6 +1378,41 @@ uint32_t rayz_hip_abi_version(void) { return RAYZ_HIP_ABI_VERSION; }
 
 int rayz_hip_debug_set(uint32_t knob, long long value) {
     if (knob >= RAYZ_DEBUG_KNOBS) return fail(RAYZ_ERR_BAD_ARG, "bad debug knob %u", knob);
+    // A knob changes scheduling, never a result — and must never be able to hang the device: values a kernel's loop
+    // control cannot take are refused here (negative = back to the built-in default, always accepted).
+    if (value >= 0) {
+        auto lane_count = [](long long b) { return b >= 1 && b <= 64; }; // a threshold counted in lanes of a wave
+        switch (knob) {
+        case RAYZ_DEBUG_QUEUE_GRAB:
+            if (value < 1 || value > (1 << 20)) return fail(RAYZ_ERR_BAD_ARG, "QUEUE_GRAB %lld outside 1 .. 2^20", value);
+            break;
+        case RAYZ_DEBUG_BVH_KEEP: // keep_active | keep_stepping << 8
+            if (value >> 16 || !lane_count(value & 0xff) || !lane_count((value >> 8) & 0xff))
+                return fail(RAYZ_ERR_BAD_ARG, "BVH_KEEP 0x%llx: both thresholds must be 1 .. 64 lanes", (unsigned long long)value);
+            break;
+        case RAYZ_DEBUG_BVH_KERNEL:
+#ifdef RAYZ_EXPERIMENTS
+            if (value != 1 && value != 2) return fail(RAYZ_ERR_BAD_ARG, "BVH_KERNEL %lld: 1 or 2", value);
+#else
+            if (value != 1) return fail(RAYZ_ERR_BAD_ARG, "BVH_KERNEL %lld: this build holds the one-path kernel only (the retired two-path "
+                                                          "experiment needs -DRAYZ_EXPERIMENTS)", value);
+#endif
+            break;
+        case RAYZ_DEBUG_BVH2_KEEP: // service | blocked << 8 | swap << 16 | keep_stepping << 24
+#ifdef RAYZ_EXPERIMENTS
+            if (value >> 32 || !lane_count(value & 0xff) || !lane_count((value >> 8) & 0xff) || !lane_count((value >> 16) & 0xff) ||
+                !lane_count((value >> 24) & 0xff))
+                return fail(RAYZ_ERR_BAD_ARG, "BVH2_KEEP 0x%llx: every threshold must be 1 .. 64 lanes", (unsigned long long)value);
+#else
+            return fail(RAYZ_ERR_BAD_ARG, "BVH2_KEEP: the two-path kernel is not in this build (-DRAYZ_EXPERIMENTS)");
+#endif
+            break;
+        case RAYZ_DEBUG_LDS_PAD:
+            if (value > 160 * 1024) return fail(RAYZ_ERR_BAD_ARG, "LDS_PAD %lld exceeds a CU's LDS", value);
+            break;
+        default: break;
+        }
+    }
     g_tune.v[knob].store(value, std::memory_order_relaxed);
     return RAYZ_OK;
 }
@@ -1393,6 +1461,7 @@ uint32_t rayz_hip_chunk_schedule(const RayzRenderParams* p, uint32_t* starts, ui
     } catch (...) {
         return 0;
     }
+    if (v.size() - 1 != chunk_count(p)) return 0; // chunk_count is exact by construction: a disagreement is a bug, not a schedule
     if (starts)
         for (size_t i = 0; i < v.size() && i < capacity; ++i) starts[i] = v[i];
     return (uint32_t)v.size() - 1;

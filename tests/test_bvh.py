@@ -117,6 +117,9 @@ def test_oracle_bvh_traversal_equals_flat_list(oracle):
     bvh, sb = oracle.render_b(sd, cam, t.params())
     assert np.array_equal(flat, bvh) and sf.segments == sb.segments
     assert sf.node_tests == 0
+    # the oracle COUNTS its flat-list tests in the scan loop: every hittable, every segment (this identity pins the counter the
+    # roofline flops in bench.py are priced from; the library derives the same figure from its segment counter)
+    assert sf.sphere_tests == sf.segments * sd.n_spheres
     assert 25 < sb.node_tests / sb.segments < 50 and 3 < sb.sphere_tests / sb.segments < 8
     # and mode A's recursive traversal visits a comparable number of boxes (same tree, f64, first-hit order)
     pa = t.params()

@@ -270,3 +270,47 @@ def test_chunk_schedule_properties_and_oracle_agreement(built, oracle):
     assert lib.rayz_hip_chunk_schedule(C.byref(p), None, 0) == 0  # .. and the schedule query says "none" instead of building 2^21 entries
     p = capi.RenderParams(width=1920, height=1080, samples_per_px=1 << 25, chunk_spp=0)  # 256-sample chunks: 2^17 of them, fine
     assert lib.rayz_hip_chunk_schedule(C.byref(p), None, 0) == (1 << 17) + 4  # 2^17 - 1 chunks of 256, then 128, 64, 32, 16, 16
+
+
+def test_chunk_count_is_exact_for_every_spp(built, oracle):
+    """validate_params bounds the chunks per pixel with chunk_count(), which must never undercount the schedule that
+    chunk_schedule() then builds (round 3's `spp / 256 + 8` did, by one, for tails of 256 .. 511 samples: spp = 497 has 10
+    chunks).  rayz_hip_chunk_schedule returns 0 when the two disagree; the oracle's independent restatement gives the length."""
+    lib, olib = capi.load(), oracle.load()
+    buf, obuf = (C.c_uint32 * 128)(), (C.c_uint32 * 128)()
+    worst = 0
+    for spp in list(range(64, 20001)) + [(1 << k) + d for k in range(15, 26) for d in (-1, 0, 1, 255, 256, 257, 497)]:
+        p = capi.RenderParams(width=1920, height=1080, samples_per_px=spp)
+        n = lib.rayz_hip_chunk_schedule(C.byref(p), buf, 128)
+        m = olib.rayz_oracle_chunk_schedule(C.byref(p), obuf, 128)
+        assert n == m and n != 0, (spp, n, m)
+        if n < 127:
+            assert list(buf[: n + 1]) == list(obuf[: n + 1]), spp
+        worst = max(worst, n - spp // 256)
+    assert worst == 9  # the bound the old formula should have used; 497 -> 1 full chunk + 9 in the tail
+    p = capi.RenderParams(width=1920, height=1080, samples_per_px=497)
+    assert lib.rayz_hip_chunk_schedule(C.byref(p), buf, 128) == 10
+
+
+def test_debug_knobs_that_could_hang_a_kernel_are_refused(built):
+    """rayz_hip_debug_set changes scheduling only, and must not be able to hang the device: a threshold byte of 0 lanes
+    (round 3: keep_stepping = 0 made trace_kernel_bvh's box-step loop spin with no lane stepping), thresholds above a wave's 64
+    lanes, a zero queue reservation and the retired two-path kernel (not in this build) are BAD_ARG; negative = default."""
+    lib = capi.load()
+    ok = lambda knob, v: lib.rayz_hip_debug_set(knob, v)  # noqa: E731
+    try:
+        for bad in (20, 20 | (0 << 8), 0 | (18 << 8), 0, 65 | (18 << 8), 20 | (65 << 8), 20 | (18 << 8) | (1 << 16)):
+            assert ok(capi.DEBUG_BVH_KEEP, bad) == capi.ERR_BAD_ARG, hex(bad)
+            assert b"BVH_KEEP" in lib.rayz_hip_last_error()
+        for good in (20 | (18 << 8), 1 | (1 << 8), 64 | (64 << 8), -1):
+            assert ok(capi.DEBUG_BVH_KEEP, good) == capi.OK, hex(good)
+        assert ok(capi.DEBUG_QUEUE_GRAB, 0) == capi.ERR_BAD_ARG and ok(capi.DEBUG_QUEUE_GRAB, 1 << 21) == capi.ERR_BAD_ARG
+        assert ok(capi.DEBUG_QUEUE_GRAB, 64) == capi.OK
+        assert ok(capi.DEBUG_BVH_KERNEL, 2) == capi.ERR_BAD_ARG and b"RAYZ_EXPERIMENTS" in lib.rayz_hip_last_error()
+        assert ok(capi.DEBUG_BVH_KERNEL, 1) == capi.OK
+        assert ok(capi.DEBUG_BVH2_KEEP, 40 | (10 << 8) | (6 << 16) | (18 << 24)) == capi.ERR_BAD_ARG
+        assert ok(capi.DEBUG_LDS_PAD, 1 << 20) == capi.ERR_BAD_ARG
+        assert ok(99, 1) == capi.ERR_BAD_ARG
+    finally:
+        for k in (capi.DEBUG_BVH_KEEP, capi.DEBUG_QUEUE_GRAB, capi.DEBUG_BVH_KERNEL, capi.DEBUG_BVH2_KEEP, capi.DEBUG_LDS_PAD):
+            lib.rayz_hip_debug_set(k, -1)

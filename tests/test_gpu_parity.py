@@ -291,28 +291,28 @@ def test_full_size_config3_spot_pixels_and_counters(gpu, oracle):
     assert rate > 170.0, f"flat-list kernel at {rate:.1f} Msamples/s: check SGPR spills in trace_kernel's scan loop"
 
 
-def test_bvh_kernels_one_and_two_paths_per_lane_are_bit_identical(gpu, oracle):
-    """trace_kernel_bvh2 (two paths per lane, the f32 default) and trace_kernel_bvh (one; selected through
-    rayz_hip_debug_set) differ in scheduling only: same image as each other and as the oracle, same segment count,
-    whatever the scheduling thresholds."""
+def test_bvh_kernel_scheduling_thresholds_change_no_result(gpu, oracle):
+    """trace_kernel_bvh's scheduling thresholds (rayz_hip_debug_set BVH_KEEP = keep_active | keep_stepping << 8: when a
+    wave leaves the box steps for the leaf phase, and the rounds for the shading pass) change which lane does what when,
+    never a result: same image as the oracle and the same segment count at the extremes 1 and 64 and in between, f32 and
+    f64, both node-record formats' scenes.  (The retired two-paths-per-lane kernel is no longer in the product library:
+    -DRAYZ_EXPERIMENTS, tools/bvh2_bench.py.)"""
     from rayz_amd import render
 
     try:
         for t in (tracer.randomBouncing(64, -20, 20, seed=42), _custom_scene(), tracer.triangleMesh(64, 12, seed=3)):
             t.samples_per_px, t.max_bounces = 5, 12
-            t.set_gpu(render_seed=8, traversal=capi.TRAVERSAL_BVH)
-            scene, cam, p = t.scene_desc(), t.camera_desc(), t.params()
-            want, ost = oracle.render_b(scene, cam, p)
-            for kernel, keep in ((2, -1), (1, -1), (2, 1 | (1 << 8) | (1 << 16) | (1 << 24)), (2, 64 | (64 << 8) | (64 << 16) | (63 << 24)),
-                                 (2, 20 | (3 << 8) | (2 << 16) | (40 << 24))):
-                render.debug_set(capi.DEBUG_BVH_KERNEL, kernel)
-                render.debug_set(capi.DEBUG_BVH2_KEEP, keep)
-                got, gst = gpu.render_host(scene, cam, p)
-                assert_images_equal(got, want, f"BVH kernel {kernel} keep {keep:#x}")
-                assert gst.segments == ost.segments
+            for precision in (capi.PRECISION_F32, capi.PRECISION_F64):
+                t.set_gpu(render_seed=8, traversal=capi.TRAVERSAL_BVH, precision=precision)
+                scene, cam, p = t.scene_desc(), t.camera_desc(), t.params()
+                want, ost = oracle.render_b(scene, cam, p)
+                for keep in (-1, 1 | (1 << 8), 64 | (64 << 8), 64 | (1 << 8), 1 | (64 << 8), 20 | (3 << 8), 40 | (24 << 8)):
+                    render.debug_set(capi.DEBUG_BVH_KEEP, keep)
+                    got, gst = gpu.render_host(scene, cam, p)
+                    assert_images_equal(got, want, f"BVH keep {keep:#x} precision {precision}")
+                    assert gst.segments == ost.segments
     finally:
-        render.debug_set(capi.DEBUG_BVH_KERNEL, -1)
-        render.debug_set(capi.DEBUG_BVH2_KEEP, -1)
+        render.debug_set(capi.DEBUG_BVH_KEEP, -1)
 
 
 def test_f32_kernel_is_unbiased_against_f64_and_mode_a(gpu, oracle):

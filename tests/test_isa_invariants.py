@@ -39,7 +39,7 @@ def test_no_instruction_touches_the_node_fetch_registers_in_flight(tmp_path):
     subprocess.run([hipcc, *flags, "--cuda-device-only", "-S", "-o", str(asm), os.path.join(ROOT, "rayz_amd", "csrc", "rayz_hip.hip")],
                    check=True, capture_output=True, timeout=600)
     kernels = _kernels(asm.read_text())
-    assert len(kernels) >= 4, sorted(kernels)  # f32 / f64 x two record formats (+ the two-path kernels)
+    assert len(kernels) >= 4, sorted(kernels)  # f32 / f64 x two record formats
     blocks = 0
     for name, L in kernels.items():
         for i, line in enumerate(L):

@@ -59,8 +59,8 @@ def _check_counters(gst, ost):
     nearer-child-first with both child boxes tested per visit and parks leaves / candidates for a later phase, the
     oracle walks it left-then-right like the reference; the nearest hit is order-independent, the pruning is not."""
     assert gst.segments == ost.segments
-    if ost.node_tests == 0:  # flat list: every hittable, every segment
-        assert (gst.node_tests, gst.sphere_tests) == (0, ost.sphere_tests)
+    if ost.node_tests == 0:  # flat list: every hittable, every segment — the library DERIVES its primitive-test figure from
+        assert gst.node_tests == 0  # the segment counter (segments x hittables, include/rayz_hip.h), so there is nothing to compare
         return
     assert 0.3 * ost.node_tests <= gst.node_tests <= 2.0 * ost.node_tests + 64
     # (+ up to 8 oversized hittables kept out of the GPU's tree and tested once per segment, bvh_build.hpp)
