@@ -188,13 +188,16 @@ typedef enum RayzDebugKnob {
     RAYZ_DEBUG_BVH_KEEP = 1,   /* one-path BVH kernel: keep_active | keep_stepping << 8 */
     RAYZ_DEBUG_BVH_PEEL = 2,   /* 0: walk the reference's full tree (oversized hittables stay in it) */
     RAYZ_DEBUG_BVH_TOP = 3,    /* cap on the inner-node records of the tree's top kept in LDS (default: what fits beside the stacks) */
-    RAYZ_DEBUG_BVH_KERNEL = 4, /* f32 BVH renders: 1 = one path per lane (trace_kernel_bvh, default), 2 = two (trace_kernel_bvh2) */
+    RAYZ_DEBUG_BVH_KERNEL = 4, /* f32 BVH renders: 1 = one path per lane (trace_kernel_bvh, default; the only one in the product library);
+                                  -DRAYZ_EXPERIMENTS builds: 2 = two paths per lane (trace_kernel_bvh2), 3 = walker / shader waves (trace_kernel_bvhx) */
     RAYZ_DEBUG_BVH2_KEEP = 5,  /* two-path BVH kernel: service | blocked << 8 | swap << 16 | keep_stepping << 24 */
     RAYZ_DEBUG_LDS_PAD = 6,    /* BVH kernels: unused bytes added to the workgroup's LDS request (occupancy experiments) */
     RAYZ_DEBUG_BVH_TOP_ORDER = 7, /* which inner nodes the LDS top holds: 0 = by box surface area from the root (default), 1 = breadth-first */
     RAYZ_DEBUG_BVH_NODES = 8,     /* node record format of trees built from now on: 0 = by tree size (default), 1 = f32 planes (64 B), 2 = 16-bit plane indices (32 B) */
     RAYZ_DEBUG_BVH_SPLIT = 9,     /* how trees built from now on split a node: 0 = surface-area heuristic (default), 1 = the reference's median split */
-    RAYZ_DEBUG_KNOBS = 10
+    RAYZ_DEBUG_BVHX = 10,         /* exchange kernel (RAYZ_DEBUG_BVH_KERNEL = 3, -DRAYZ_EXPERIMENTS builds only): slots per walker wave | exchange threshold << 8 |
+                                     shader's minimum batch << 16 | its patience << 24 | its priority << 32 */
+    RAYZ_DEBUG_KNOBS = 11
 } RayzDebugKnob;
 int rayz_hip_debug_set(uint32_t knob, long long value);
 

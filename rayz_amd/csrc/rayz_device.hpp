@@ -124,6 +124,9 @@ template <class R> struct TraceArgs {
     uint32_t bvh_top_words;   // BVH kernel: u32s of LDS taken by the copy of the tree's top (the per-lane stacks follow)
     uint32_t bvh_big_words;   // BVH kernel: where (in u32s of LDS) the oversized hittables' records are kept, after the stacks
     uint32_t queue_grab;     // work items a wave reserves per atomic on the queue head (kQueueGrab; scheduling only)
+    uint32_t x_words;        // exchange kernel (trace_kernel_bvhx): where (in u32s of LDS) its exchange area starts
+    uint32_t x_slots;        //   ray slots per walker wave
+    uint32_t x_cfg;          //   scheduling: exchange when this many lanes finished | shader's minimum batch << 8 | its patience << 16 | its priority << 24
 };
 
 // ---- small helpers -----------------------------------------------------------------------------
@@ -1986,6 +1989,447 @@ template <class R, bool QUANT> __global__ __launch_bounds__(256, RAYZ_BVH2_WAVES
     }
 }
 #endif // RAYZ_EXPERIMENTS
+
+#ifdef RAYZ_EXPERIMENTS
+// ---- persistent trace kernel, BVH traversal, WALKER and SHADER waves (round-4 experiment) --------------------------------
+// trace_kernel_bvh runs its shading pass (shade -> retire / pop / start -> per-segment set-up: ~1,700 vector instructions) with
+// ~48 of 64 lanes, and its box steps with ~42 while ~13 lanes wait, finished, for that pass (profiles/r03, r04).  Here the 16
+// waves of the workgroup take fixed roles: kXWalkers waves only walk, kXShaders waves only run the pass, and rays travel
+// between them through small per-walker-wave slot sets in LDS — a walker lane whose walk is complete hands its whole path
+// (ray + context, 7 x 16 B) to a FREE slot of its wave and takes a READY one (11 x 16 B: + the set-up's constants); the shader
+// wave bound to that walker collects FINISHED slots from its 2-3 walker waves until it has a full wave of them, runs the pass
+// on 64 lanes and writes each result back IN PLACE (FINISHED -> READY).  Every slot state has one writer per transition and
+// a wave's LDS operations complete in order, so the hand-over needs no atomics: data first, then the state word.  Births and
+// deaths of paths happen only in the shader (a finished chunk is retired and the next item popped in place), so the number of
+// paths bound to a walker wave is constant, 64 + x_slots / 2: some slot is always FREE or about to become READY (no deadlock).
+// Same per-path arithmetic, queue and summation tree as the other kernels: the image is identical bit for bit.
+#ifndef RAYZ_BVHX_SHADERS
+#define RAYZ_BVHX_SHADERS 4
+#endif
+constexpr uint32_t kXShaders = RAYZ_BVHX_SHADERS, kXWalkers = 16 - kXShaders, kXWalkerLanes = kXWalkers * 64;
+constexpr uint32_t kXFree = 0, kXFinished = 1, kXReady = 2; // slot states
+constexpr uint32_t kXChunksF = 7, kXChunksR = 11;           // 16-byte pieces of a record: walker -> shader, shader -> walker
+// exchange area (u32 words from A.x_words): [s] done flag of shader s | [16 + w] rays held in the lanes of walker w | [32] abort |
+// [64 + 64 w + i] state of slot i of walker w | from kXScratchWords: two 64-byte rank -> slot tables per wave | from kXSlotWords:
+// the slots, piece c of slot i of walker w = the f4 at (w * 11 + c) * x_slots + i (piece-major: the lanes of a wave touch
+// consecutive 16-byte pieces — conflict-free ds_read_b128 / ds_write_b128)
+constexpr uint32_t kXScratchWords = 64 + 16 * 64, kXSlotWords = kXScratchWords + 16 * 32;
+__host__ __device__ constexpr size_t bvhx_exchange_bytes(uint32_t ns) { return (size_t)kXSlotWords * 4 + (size_t)kXWalkers * kXChunksR * ns * 16; }
+constexpr uint32_t kXSpinLimit = 1u << 22; // idle polls (s_sleep) before a wave gives up and aborts the launch: bounded, never a hang
+
+__device__ __forceinline__ void set_prio(uint32_t p) { // s_setprio takes an immediate; p is wave-uniform
+    if (p == 3u) __builtin_amdgcn_s_setprio(3);
+    else if (p == 2u) __builtin_amdgcn_s_setprio(2);
+    else if (p == 1u) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+}
+template <bool QUANT> __global__ __launch_bounds__(1024, 1) void trace_kernel_bvhx(const TraceArgs<float> A) {
+    typedef float R;
+    typedef f4 r4;
+    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t n_nodes = A.sc.bvh_n_nodes, NS = A.x_slots;
+    const float tmin32 = round_down_f32(A.tmin);
+    extern __shared__ uint32_t lds_words[];
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)lds_words != 0u) { // see trace_kernel_bvh
+        if (threadIdx.x == 0) A.counters[31] = 1ull;
+        return;
+    }
+    f4* top = (f4*)lds_words;
+    for (uint32_t k = threadIdx.x; k < A.sc.bvh_top / 16u; k += 1024u) top[k] = A.sc.bvh_nodes[k];
+    const f4* nodes_base = scalar_base(A.sc.bvh_nodes);
+    unsigned char* big_lds = (unsigned char*)(lds_words + A.bvh_big_words);
+    if (threadIdx.x < 2u * A.sc.bvh_n_big_leaves) { // (as trace_kernel_bvh)
+        const uint32_t desc = A.sc.bvh_big[threadIdx.x >> 1], j = threadIdx.x & 1u;
+        if (j < (desc & 3u)) {
+            const uint32_t slot = (desc >> 4) + j;
+            d4* dst64 = (d4*)(big_lds + threadIdx.x * bvh_big_entry_bytes<R>());
+            dst64[0] = A.sc.bvh_sph64[2 * slot];
+            dst64[1] = A.sc.bvh_sph64[2 * slot + 1];
+            r4* dst = (r4*)(dst64 + 2);
+            const r4* rec = A.sc.bvh_leaf + (size_t)A.sc.bvh_leaf_stride * slot;
+            dst[0] = rec[0];
+            dst[1] = rec[1];
+            dst[2] = A.sc.bvh_leaf_stride > 2u ? rec[2] : rec[1];
+        }
+    }
+    // the exchange area: every walker lane starts with a finished "null" path (no item, not alive: the shader pops one into it),
+    // and half of every walker's slots start FINISHED with such a path too
+    volatile uint32_t* xw = lds_words + A.x_words;
+    f4* slots = (f4*)(lds_words + A.x_words + kXSlotWords);
+    for (uint32_t k = threadIdx.x; k < kXSlotWords; k += 1024u) {
+        uint32_t v = 0u;
+        if (k >= 16u && k < 16u + kXWalkers) v = 64u;
+        if (k >= 64u && k < 64u + 64u * kXWalkers) v = ((k & 63u) < NS / 2u) ? kXFinished : kXFree;
+        xw[k] = v;
+    }
+    for (uint32_t k = threadIdx.x; k < kXWalkers * kXChunksR * NS; k += 1024u) slots[k] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (wv < kXWalkers) lds_words[A.bvh_top_words + kXWalkerLanes + threadIdx.x] = kBvhDone; // the sentinel under every walker lane's stack
+    __syncthreads();
+
+    const uint32_t x_min = A.x_cfg & 0xffu, x_batch = (A.x_cfg >> 8) & 0xffu, x_patience = (A.x_cfg >> 16) & 0xffu, x_prio = (A.x_cfg >> 24) & 3u,
+                   w_prio_n = (A.x_cfg >> 26) & 3u, w_prio_lc = (A.x_cfg >> 28) & 3u, w_prio_x = (A.x_cfg >> 30) & 3u;
+    volatile unsigned char* scr = (volatile unsigned char*)(xw + kXScratchWords) + 128u * wv;
+    // a path, as it travels
+    Pcg32 g{0, 1};
+    V<R> o{0, 0, 0}, d{0, 0, 1}, ud{0, 0, 1}, thr{1, 1, 1}, acc{0, 0, 0};
+    R time = 0;
+    uint32_t item = 0, px = 0, py = 0, s_cur = 0, s_end = 0, segflags = 0; // segflags: segments so far | alive << 30 | has_item << 31
+    BvhQuery<R> q;
+    q.qa = {1.0f, 1.0f, 1.0f};
+    q.qb = {0.0f, 0.0f, 0.0f};
+    q.tb32 = 0.0f;
+    q.inv_a2 = 1.0;
+    q.tbest = R(0);
+    q.ibest = -1;
+    q.cur = kBvhDone;
+    q.sp = 0;
+    q.top = kBvhDone;
+    q.lb.make(ud, o);
+    uint32_t nseg = 0, sphere_tests = 0, node_tests = 0;
+#ifdef RAYZ_BVH_PROFILE
+    unsigned long long x_fetch = 0;
+#define RAYZ_XPROF_FETCH , x_fetch
+    unsigned long long xp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, xt0 = __builtin_amdgcn_s_memtime();
+#define RAYZ_XPROF_T(k) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); xp[k] += now_ - xt0; xt0 = now_; }
+#define RAYZ_XPROF_N(k, n) { xp[k] += (unsigned long long)(n); }
+#else
+#define RAYZ_XPROF_FETCH
+#define RAYZ_XPROF_T(k)
+#define RAYZ_XPROF_N(k, n)
+#endif
+
+    if (wv < kXWalkers) {
+        // ================================================ WALKER ================================================
+        uint32_t* stack = lds_words + A.bvh_top_words + kXWalkerLanes + threadIdx.x; // (one guard row under entry 0)
+        volatile uint32_t* xs = xw + 64u + 64u * wv;
+        f4* my_slots = slots + (size_t)wv * kXChunksR * NS;
+        const uint32_t my_shader = wv % kXShaders;
+        bool has_ray = true;
+        for (uint32_t spins = 0;;) {
+            // ---- exchange: finished paths out, ready paths in ----
+            {
+                const uint32_t st = lane < NS ? xs[lane] : 3u;
+                const bool fin = has_ray && q.cur == kBvhDone;
+                const unsigned long long m_fin = __ballot(fin), m_free = __ballot(st == kXFree), m_ready = __ballot(st == kXReady);
+                const uint32_t n_fin = (uint32_t)__popcll(m_fin), n_free = (uint32_t)__popcll(m_free), n_dep = n_fin < n_free ? n_fin : n_free;
+                if (n_dep != 0u) {
+                    if (st == kXFree) scr[__builtin_amdgcn_mbcnt_hi((uint32_t)(m_free >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_free, 0u))] = (unsigned char)lane;
+                    const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_fin >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_fin, 0u));
+                    asm volatile("" ::: "memory");
+                    if (fin && r < n_dep) {
+                        const uint32_t slot = scr[r];
+                        f4* rec = my_slots + slot;
+                        rec[0 * NS] = f4{o.x, o.y, o.z, time};
+                        rec[1 * NS] = f4{d.x, d.y, d.z, q.tbest};
+                        rec[2 * NS] = f4{ud.x, ud.y, ud.z, Bits<float>::from((uint32_t)q.ibest)};
+                        rec[3 * NS] = f4{thr.x, thr.y, thr.z, Bits<float>::from(segflags)};
+                        rec[4 * NS] = f4{acc.x, acc.y, acc.z, Bits<float>::from(item)};
+                        rec[5 * NS] = f4{Bits<float>::from((uint32_t)g.state), Bits<float>::from((uint32_t)(g.state >> 32)), Bits<float>::from((uint32_t)g.inc),
+                                         Bits<float>::from((uint32_t)(g.inc >> 32))};
+                        rec[6 * NS] = f4{Bits<float>::from(px), Bits<float>::from(py), Bits<float>::from(s_cur), Bits<float>::from(s_end)};
+                        asm volatile("" ::: "memory");
+                        xs[slot] = kXFinished; // after the record (LDS keeps a wave's order)
+                        has_ray = false;
+                    }
+                }
+                const unsigned long long m_empty = __ballot(!has_ray);
+                const uint32_t n_empty = (uint32_t)__popcll(m_empty), n_ready = (uint32_t)__popcll(m_ready), n_take = n_empty < n_ready ? n_empty : n_ready;
+                // the rays this wave's lanes hold, as its shader's end test sees them: never below the truth — written after the
+                // deposits' state words and before the takes'
+                asm volatile("" ::: "memory");
+                if (lane == 0u) xw[16u + wv] = 64u - n_empty + n_take;
+                asm volatile("" ::: "memory");
+                if (n_take != 0u) {
+                    if (st == kXReady) scr[64u + __builtin_amdgcn_mbcnt_hi((uint32_t)(m_ready >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_ready, 0u))] = (unsigned char)lane;
+                    const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_empty >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_empty, 0u));
+                    asm volatile("" ::: "memory");
+                    if (!has_ray && r < n_take) {
+                        const uint32_t slot = scr[64u + r];
+                        const f4* rec = my_slots + slot;
+                        const f4 c0 = rec[0 * NS], c1 = rec[1 * NS], c2 = rec[2 * NS], c3 = rec[3 * NS], c4 = rec[4 * NS], c5 = rec[5 * NS],
+                                 c6 = rec[6 * NS], c7 = rec[7 * NS], c8 = rec[8 * NS], c9 = rec[9 * NS], c10 = rec[10 * NS];
+                        asm volatile("" ::: "memory");
+                        xs[slot] = kXFree; // after the reads
+                        o = {c0.x, c0.y, c0.z}, time = c0.w;
+                        d = {c1.x, c1.y, c1.z}, q.tbest = c1.w;
+                        ud = {c2.x, c2.y, c2.z}, q.ibest = (int)bits(c2.w);
+                        thr = {c3.x, c3.y, c3.z}, segflags = bits(c3.w);
+                        acc = {c4.x, c4.y, c4.z}, item = bits(c4.w);
+                        g.state = (unsigned long long)bits(c5.x) | ((unsigned long long)bits(c5.y) << 32);
+                        g.inc = (unsigned long long)bits(c5.z) | ((unsigned long long)bits(c5.w) << 32);
+                        px = bits(c6.x), py = bits(c6.y), s_cur = bits(c6.z), s_end = bits(c6.w);
+                        q.qa = {c7.x, c7.y, c7.z};
+                        q.qb = {c7.w, c8.x, c8.y};
+                        q.inv_a2 = __builtin_bit_cast(double, (unsigned long long)bits(c8.z) | ((unsigned long long)bits(c8.w) << 32));
+                        q.lb.b.e1x = c9.x, q.lb.b.e1z = c9.y, q.lb.b.e2x = c9.z, q.lb.b.e2y = c9.w;
+                        q.lb.b.e2z = c10.x, q.lb.b.k1 = c10.y, q.lb.b.k2 = c10.z;
+                        q.cur = n_nodes ? 0u : kBvhDone;
+                        q.sp = 0;
+                        q.top = kBvhDone;
+                        has_ray = true;
+                    }
+                }
+            }
+            RAYZ_XPROF_T(0)
+            RAYZ_XPROF_N(3, 1)
+            if (__ballot(q.cur != kBvhDone) == 0ull) { // nobody to walk: wait for ready paths, or for free slots — or the end
+                if (__ballot(has_ray) == 0ull && xw[my_shader] != 0u) break;
+                if (xw[32] != 0u) break;
+                if (++spins > kXSpinLimit) {
+                    xw[32] = 1u;
+                    if (lane == 0u) A.counters[31] = 2ull;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+                RAYZ_XPROF_T(1)
+                continue;
+            }
+            spins = 0;
+            RAYZ_XPROF_N(4, __popcll(__ballot(q.cur != kBvhDone)))
+            RAYZ_XPROF_N(5, __popcll(__ballot(has_ray)))
+            RAYZ_XPROF_N(6, 1)
+            // ---- rounds of (N) box steps, (L) leaf tests, (C) candidate roots, as in trace_kernel_bvh ----
+            const int keep_stepping = (int)((A.bvh_keep >> 8) & 0xffu);
+            for (;;) {
+                bool can_step = q.cur < kBvhDone;
+                int n_can = __popcll(__ballot(can_step));
+                bool run = n_can != 0 && (n_can >= keep_stepping || __ballot((int32_t)q.cur < 0) == 0ull);
+                set_prio(w_prio_n);
+                while (run) {
+                    if (can_step) bvh_node_step<R, kXWalkerLanes, QUANT>(A.sc, nodes_base, q, tmin32, stack RAYZ_XPROF_FETCH);
+                    {
+                        const bool again = q.cur < kBvhDone;
+                        node_tests += 2u * (uint32_t)__popcll(__ballot(again));
+                        if (again) bvh_node_step<R, kXWalkerLanes, QUANT>(A.sc, nodes_base, q, tmin32, stack RAYZ_XPROF_FETCH);
+                    }
+                    node_tests += 2u * (uint32_t)n_can;
+                    can_step = q.cur < kBvhDone;
+                    n_can = __popcll(__ballot(can_step));
+                    run = n_can != 0 && (n_can >= keep_stepping || __ballot((int32_t)q.cur < 0) == 0ull);
+                }
+                set_prio(w_prio_lc);
+                const bool parked = (int32_t)q.cur < 0;
+                if (__ballot(parked) != 0ull) {
+                    uint32_t cand0 = 0, cand1 = 0;
+                    int pool0 = 0, pool1 = 0;
+                    if (parked) { // phase L
+                        const uint32_t leaf = q.cur & ~kBvhLeafFlag;
+                        sphere_tests += leaf & 3u;
+                        bvh_pop<R, kXWalkerLanes>(q, stack);
+                        bvh_leaf_pair<R>(A.sc, q, leaf, o, d, ud, time, A.tmin, cand0, cand1, pool0, pool1);
+                    }
+                    if (__ballot((cand0 | cand1) != 0u) != 0ull) { // phase C
+                        const uint32_t c0 = cand0 != 0u ? cand0 : cand1, c1 = cand0 != 0u ? cand1 : 0u;
+                        const int p0 = cand0 != 0u ? pool0 : pool1;
+                        if (c0 != 0u) bvh_candidate<R>(A.sc, q, c0 - 1u, p0, o, d, time, A.tmin);
+                        if (__ballot(c1 != 0u) != 0ull) {
+                            if (c1 != 0u) bvh_candidate<R>(A.sc, q, c1 - 1u, pool1, o, d, time, A.tmin);
+                        }
+                    }
+                }
+                if (__ballot(q.cur != kBvhDone) == 0ull) break;
+                if ((uint32_t)__popcll(__ballot(has_ray && q.cur == kBvhDone)) >= x_min) break; // enough finished paths to hand over
+            }
+            set_prio(w_prio_x);
+            RAYZ_XPROF_T(2)
+        }
+#ifdef RAYZ_BVH_PROFILE
+        if (lane == 0) for (int k = 0; k < 7; ++k) atomicAdd(&A.counters[4 + k], xp[k]);
+#endif
+    } else {
+        // ================================================ SHADER ================================================
+        const uint32_t sh = wv - kXWalkers;
+        WaveQueue wq;
+        uint32_t k0 = 0, waited = 0, spins = 0;
+        set_prio(x_prio);
+        uint32_t nw = 0;
+        for (uint32_t k = 0; k < 3u; ++k) nw += (sh + k * kXShaders < kXWalkers) ? 1u : 0u;
+        for (;;) {
+            // ---- collect FINISHED slots of my walkers (starting with a different walker each time) ----
+            uint32_t st[3];
+            unsigned long long m[3];
+            uint32_t n = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < 3u; ++j) {
+                const uint32_t k = (k0 + j) % 3u, w = sh + k * kXShaders;
+                st[j] = (k < nw && lane < NS) ? xw[64u + 64u * w + lane] : 3u;
+                m[j] = __ballot(st[j] == kXFinished);
+                n += (uint32_t)__popcll(m[j]);
+            }
+            if (n == 0u) {
+                bool over = false;
+                if (queue_empty<R>(wq, A)) { // nothing is born any more: over when no path is left — slots, lanes, slots again
+                    bool busy = false;
+#pragma unroll
+                    for (uint32_t j = 0; j < 3u; ++j) busy = busy || (st[j] == kXFinished || st[j] == kXReady);
+                    uint32_t rays = 0;
+                    for (uint32_t k = 0; k < nw; ++k) rays += xw[16u + sh + k * kXShaders];
+                    asm volatile("" ::: "memory");
+                    for (uint32_t k = 0; k < nw; ++k) {
+                        const uint32_t s2 = lane < NS ? xw[64u + 64u * (sh + k * kXShaders) + lane] : 0u;
+                        busy = busy || s2 != kXFree;
+                    }
+                    over = __ballot(busy) == 0ull && rays == 0u;
+                }
+                if (over) {
+                    if (lane == 0u) xw[sh] = 1u;
+                    break;
+                }
+                if (xw[32] != 0u) break;
+                if (++spins > kXSpinLimit) {
+                    xw[32] = 1u;
+                    if (lane == 0u) A.counters[31] = 2ull;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+                RAYZ_XPROF_T(0)
+                continue;
+            }
+            spins = 0;
+            if (n < x_batch && waited < x_patience) { // let the batch fill
+                ++waited;
+                __builtin_amdgcn_s_sleep(1);
+                RAYZ_XPROF_T(1)
+                continue;
+            }
+            RAYZ_XPROF_T(1)
+            RAYZ_XPROF_N(3, 1)
+            RAYZ_XPROF_N(4, n < 64u ? n : 64u)
+            RAYZ_XPROF_N(5, n)
+            waited = 0;
+            uint32_t off = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < 3u; ++j) {
+                const uint32_t k = (k0 + j) % 3u;
+                const uint32_t r = off + __builtin_amdgcn_mbcnt_hi((uint32_t)(m[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[j], 0u));
+                if (st[j] == kXFinished && r < 64u) scr[r] = (unsigned char)((k << 6) | lane); // (x_slots <= 64 and k <= 2: fits a byte... k << 6 | lane < 192)
+                off += (uint32_t)__popcll(m[j]);
+            }
+            k0 = (k0 + 1u) % 3u;
+            asm volatile("" ::: "memory");
+            const bool have = lane < (n < 64u ? n : 64u);
+            uint32_t code = 0;
+            if (have) code = scr[lane];
+            const uint32_t w_of = sh + (code >> 6) * kXShaders, slot = code & 63u;
+            f4* rec = slots + (size_t)w_of * kXChunksR * NS + slot;
+            bool alive = false, has_item = false, fresh = false;
+            uint32_t seg = 0;
+            if (have) {
+                const f4 c0 = rec[0 * NS], c1 = rec[1 * NS], c2 = rec[2 * NS], c3 = rec[3 * NS], c4 = rec[4 * NS], c5 = rec[5 * NS], c6 = rec[6 * NS];
+                o = {c0.x, c0.y, c0.z}, time = c0.w;
+                d = {c1.x, c1.y, c1.z}, q.tbest = c1.w;
+                ud = {c2.x, c2.y, c2.z}, q.ibest = (int)bits(c2.w);
+                thr = {c3.x, c3.y, c3.z}, segflags = bits(c3.w);
+                acc = {c4.x, c4.y, c4.z}, item = bits(c4.w);
+                g.state = (unsigned long long)bits(c5.x) | ((unsigned long long)bits(c5.y) << 32);
+                g.inc = (unsigned long long)bits(c5.z) | ((unsigned long long)bits(c5.w) << 32);
+                px = bits(c6.x), py = bits(c6.y), s_cur = bits(c6.z), s_end = bits(c6.w);
+                alive = (segflags >> 30) & 1u, has_item = (segflags >> 31) & 1u, seg = segflags & 0x3fffffffu;
+            }
+            // ---- the pass, as in trace_kernel_bvh: shade, retire / pop / start, per-segment set-up ----
+            if (alive) {
+                nseg++;
+                seg++;
+                bool cont = shade<R>(A.sc, g, o, d, ud, time, q.tbest, q.ibest, thr, acc);
+                if (seg >= A.max_bounces) cont = false;
+                alive = cont;
+                fresh = cont;
+            }
+            if (have && !alive && has_item && s_cur == s_end) {
+                A.partial[item] = r4{acc.x, acc.y, acc.z, R(0)};
+                has_item = false;
+            }
+            {
+                const bool popping = __ballot(have && !alive && !has_item && !queue_empty<R>(wq, A)) != 0ull;
+                uint32_t got_item = 0;
+                if (queue_pop<R>(A, wq, lane, have && !alive && !has_item && !queue_empty<R>(wq, A), got_item)) {
+                    item = got_item;
+                    has_item = true;
+                    const uint32_t k = place_item<R, true>(A, item, px, py);
+                    s_cur = A.chunk_start[k];
+                    s_end = A.chunk_start[k + 1];
+                    acc = {R(0), R(0), R(0)};
+                }
+                if (popping && nseg > RAYZ_STAT_SPILL) {
+                    atomicAdd(&A.counters[3], (unsigned long long)sphere_tests);
+                    atomicAdd(&A.counters[1], (unsigned long long)nseg);
+                    sphere_tests = nseg = 0;
+                }
+            }
+            if (have && !alive && has_item) {
+                const unsigned long long pixel_index = (unsigned long long)py * A.width + px;
+                g.seed_path(A.seed, pixel_index * A.spp + s_cur);
+                camera_ray<R>(A.cam, g, px, py, o, d, time);
+                thr = {R(1), R(1), R(1)};
+                seg = 0;
+                s_cur++;
+                alive = true;
+                fresh = true;
+            }
+            if (fresh) {
+                ud = unit(d);
+                bvh_begin<R, QUANT>(q, A.sc, o, d, ud, n_nodes);
+            }
+            if (A.sc.bvh_n_big_leaves != 0u && __ballot(fresh) != 0ull) {
+                if (fresh) {
+                    for (uint32_t k = 0; k < A.sc.bvh_n_big_leaves; ++k) {
+                        const uint32_t desc = A.sc.bvh_big[k];
+                        sphere_tests += desc & 3u;
+                        for (uint32_t j = 0; j < (desc & 3u); ++j) {
+                            const d4* rec64 = (const d4*)(big_lds + (2u * k + j) * bvh_big_entry_bytes<R>());
+                            const r4* brec = (const r4*)(rec64 + 2);
+                            const r4 c = brec[0], v = brec[1], w3 = brec[2];
+                            if (bvh_leaf_eval<R>(A.sc, q, desc, j, c, v, o, d, ud, time, A.tmin, &w3) != 0u)
+                                bvh_candidate_eval<R>(q, rec64[0], rec64[1], (int)bits(v.w), o, d, time, A.tmin);
+                        }
+                    }
+                }
+            }
+            // ---- back, in place: a living path READY for its walker; a path that ended with the queue dry frees its slot ----
+            if (have) {
+                volatile uint32_t* state = xw + 64u + 64u * w_of + slot;
+                if (alive) {
+                    segflags = seg | (1u << 30) | ((has_item ? 1u : 0u) << 31);
+                    const unsigned long long ia = __builtin_bit_cast(unsigned long long, q.inv_a2);
+                    rec[0 * NS] = f4{o.x, o.y, o.z, time};
+                    rec[1 * NS] = f4{d.x, d.y, d.z, q.tbest};
+                    rec[2 * NS] = f4{ud.x, ud.y, ud.z, Bits<float>::from((uint32_t)q.ibest)};
+                    rec[3 * NS] = f4{thr.x, thr.y, thr.z, Bits<float>::from(segflags)};
+                    rec[4 * NS] = f4{acc.x, acc.y, acc.z, Bits<float>::from(item)};
+                    rec[5 * NS] = f4{Bits<float>::from((uint32_t)g.state), Bits<float>::from((uint32_t)(g.state >> 32)), Bits<float>::from((uint32_t)g.inc),
+                                     Bits<float>::from((uint32_t)(g.inc >> 32))};
+                    rec[6 * NS] = f4{Bits<float>::from(px), Bits<float>::from(py), Bits<float>::from(s_cur), Bits<float>::from(s_end)};
+                    rec[7 * NS] = f4{q.qa.x, q.qa.y, q.qa.z, q.qb.x};
+                    rec[8 * NS] = f4{q.qb.y, q.qb.z, Bits<float>::from((uint32_t)ia), Bits<float>::from((uint32_t)(ia >> 32))};
+                    rec[9 * NS] = f4{q.lb.b.e1x, q.lb.b.e1z, q.lb.b.e2x, q.lb.b.e2y};
+                    rec[10 * NS] = f4{q.lb.b.e2z, q.lb.b.k1, q.lb.b.k2, 0.0f};
+                    asm volatile("" ::: "memory");
+                    *state = kXReady;
+                } else {
+                    *state = kXFree;
+                }
+            }
+            asm volatile("" ::: "memory");
+            RAYZ_XPROF_T(2)
+        }
+#ifdef RAYZ_BVH_PROFILE
+        if (lane == 0) for (int k = 0; k < 6; ++k) atomicAdd(&A.counters[12 + k], xp[k]);
+#endif
+    }
+    unsigned long long t0 = nseg, t1 = node_tests, t2 = sphere_tests;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        t0 += __shfl_xor(t0, off);
+        t2 += __shfl_xor(t2, off);
+    }
+    if (lane == 0) {
+        atomicAdd(&A.counters[1], t0);
+        atomicAdd(&A.counters[2], t1);
+        atomicAdd(&A.counters[3], t2);
+    }
+}
+#endif // RAYZ_EXPERIMENTS (exchange kernel)
 
 // ---- pixel = (Σ_chunks partial) · (1/spp), chunk order: src/renderer.zig:94-95 ---------------------
 template <class R>

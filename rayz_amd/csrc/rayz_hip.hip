@@ -262,7 +262,7 @@ struct RayzScene {
     unsigned long long* counters = nullptr; // [0] queue head, [1] segments
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipStream_t last_stream = nullptr;
-    bool rendered = false, last_bvh = false, last_two_paths = false;
+    bool rendered = false, last_bvh = false, last_two_paths = false, last_exchange = false;
     RayzRenderStats last{};
 };
 
@@ -860,8 +860,10 @@ int render_impl(RayzScene* s, const DeviceCtx& ctx, SceneBuffers<R>& b, const Ra
     // 19 % slower) is a retired experiment: only a -DRAYZ_EXPERIMENTS build contains it (RAYZ_DEBUG_BVH_KERNEL = 2).
 #ifdef RAYZ_EXPERIMENTS
     const bool two_paths = use_bvh && sizeof(R) == 4 && tuning(RAYZ_DEBUG_BVH_KERNEL, 1) == 2;
+    // .. and the walker / shader-wave form (trace_kernel_bvhx, f32 only): round 4's experiment, RAYZ_DEBUG_BVH_KERNEL = 3
+    const bool exchange = use_bvh && sizeof(R) == 4 && tuning(RAYZ_DEBUG_BVH_KERNEL, 1) == 3;
 #else
-    const bool two_paths = false;
+    const bool two_paths = false, exchange = false;
 #endif
     // scheduling thresholds of the BVH kernel (no effect on results; rayz_hip_debug_set refuses values outside 1 .. 64 lanes)
     A.bvh_keep = (uint32_t)tuning(RAYZ_DEBUG_BVH_KEEP, kBvhKeepActive | (kBvhKeepStepping << 8));
@@ -875,17 +877,41 @@ int render_impl(RayzScene* s, const DeviceCtx& ctx, SceneBuffers<R>& b, const Ra
     // the BVH kernel's LDS stack holds one entry per tree level below the root (nearer child first: the stack never
     // holds more than one entry per level); sized from THIS tree, so a shallow tree does not cap the occupancy
     // (+ one guard row under entry 0: a lane that has popped its sentinel reads ahead at index −1)
-    const size_t bvh_stack_bytes = use_bvh ? ((size_t)s->bvh_dev.depth + 3) * block * sizeof(uint32_t) : 0;
+    size_t bvh_stack_bytes = use_bvh ? ((size_t)s->bvh_dev.depth + 3) * block * sizeof(uint32_t) : 0;
+    size_t x_bytes = 0; // the exchange kernel's slot area (after the oversized hittables' records); only its walker waves have stacks
+#ifdef RAYZ_EXPERIMENTS
+    if (exchange) {
+        const long long xk = tuning(RAYZ_DEBUG_BVHX, -1);
+        const uint32_t ns = xk < 0 ? 24u : (uint32_t)(xk & 0xff), xmin = xk < 0 ? 12u : (uint32_t)((xk >> 8) & 0xff),
+                       xbatch = xk < 0 ? 48u : (uint32_t)((xk >> 16) & 0xff), xpat = xk < 0 ? 8u : (uint32_t)((xk >> 24) & 0xff),
+                       xprio = xk < 0 ? 0x6eu : (uint32_t)((xk >> 32) & 0xff); // shader | walker box steps << 2 | leaf / root phases << 4 | exchange << 6
+        A.x_slots = ns;
+        A.x_cfg = xmin | (xbatch << 8) | (xpat << 16) | (xprio << 24);
+        bvh_stack_bytes = ((size_t)s->bvh_dev.depth + 3) * kXWalkerLanes * sizeof(uint32_t);
+        x_bytes = bvhx_exchange_bytes(ns);
+        if (p->max_bounces >= (1u << 30)) return fail(RAYZ_ERR_BAD_ARG, "the exchange kernel packs flags into the segment count: max_bounces < 2^30");
+    }
+#endif
     // the tree's top: first in LDS.  The scene numbered b.bvh_top records breadth-first for the one-path kernel's workgroup;
     // a kernel whose workgroup has less LDS to spare (two paths per lane: three 256-thread workgroups per CU) keeps a prefix
     uint32_t top_records = use_bvh ? b.bvh_top : 0u;
     if (two_paths) top_records = std::min<uint32_t>(top_records, b.quantized ? 512u : 256u);
+    if (exchange) { // what the walkers' stacks and the slots leave of the budget
+        const size_t fixed = bvh_stack_bytes + (b.n_big_leaves ? kBvhBigLdsBytes : 0) + x_bytes;
+        const size_t room = fixed < kBvhLdsBudget ? kBvhLdsBudget - fixed : 0;
+        top_records = std::min<uint32_t>(top_records, (uint32_t)(room / (b.quantized ? 32 : 64)));
+        const long long cap = tuning(RAYZ_DEBUG_BVH_TOP, -1);
+        if (cap >= 0) top_records = std::min<uint32_t>(top_records, (uint32_t)cap);
+    }
     typedef void (*Kernel)(const TraceArgs<R>);
     Kernel kernel = trace_kernel<R, 1>;
     if (use_bvh) kernel = b.quantized ? trace_kernel_bvh<R, true> : trace_kernel_bvh<R, false>;
 #ifdef RAYZ_EXPERIMENTS
     if (two_paths) {
         if constexpr (sizeof(R) == 4) kernel = b.quantized ? trace_kernel_bvh2<float, true> : trace_kernel_bvh2<float, false>;
+    }
+    if (exchange) {
+        if constexpr (sizeof(R) == 4) kernel = b.quantized ? trace_kernel_bvhx<true> : trace_kernel_bvhx<false>;
     }
 #endif
     // The LDS request: top | stacks | oversized hittables' records (+ RAYZ_DEBUG_LDS_PAD unused bytes: an occupancy experiment —
@@ -894,7 +920,7 @@ int render_impl(RayzScene* s, const DeviceCtx& ctx, SceneBuffers<R>& b, const Ra
     // a SHORTER PREFIX of the top instead of failing every BVH render — the walk works with any prefix (records beyond it are
     // read from global memory), only slower.
     const size_t rec_bytes = b.quantized ? 32 : 64;
-    const size_t bvh_fixed = use_bvh ? bvh_stack_bytes + (b.n_big_leaves ? kBvhBigLdsBytes : 0) + (size_t)tuning(RAYZ_DEBUG_LDS_PAD, 0) : 0;
+    const size_t bvh_fixed = use_bvh ? bvh_stack_bytes + (b.n_big_leaves ? kBvhBigLdsBytes : 0) + x_bytes + (size_t)tuning(RAYZ_DEBUG_LDS_PAD, 0) : 0;
     size_t bvh_top_bytes = 0, bvh_lds = 0;
     for (;;) {
         bvh_top_bytes = (size_t)top_records * rec_bytes;
@@ -914,6 +940,7 @@ int render_impl(RayzScene* s, const DeviceCtx& ctx, SceneBuffers<R>& b, const Ra
     A.bvh_top_words = (uint32_t)(bvh_top_bytes / sizeof(uint32_t));
     A.bvh_big_words = (uint32_t)((bvh_top_bytes + bvh_stack_bytes) / sizeof(uint32_t));
     A.sc.bvh_top = (uint32_t)bvh_top_bytes; // the walk compares byte offsets
+    A.x_words = (uint32_t)((bvh_top_bytes + bvh_stack_bytes + (b.n_big_leaves ? kBvhBigLdsBytes : 0)) / sizeof(uint32_t));
     if (blocks_per_cu < 1) blocks_per_cu = 1;
     uint64_t grid = (uint64_t)ctx.num_cu * blocks_per_cu;
     // (a lane of the two-path kernel holds two items)
@@ -921,6 +948,7 @@ int render_impl(RayzScene* s, const DeviceCtx& ctx, SceneBuffers<R>& b, const Ra
     if (grid > want) grid = want;
 
     s->last_two_paths = two_paths;
+    s->last_exchange = exchange;
     HIP_TRY(hipMemsetAsync(s->counters, 0, 32 * sizeof(unsigned long long), stream));
     HIP_TRY(hipEventRecord(s->ev0, stream));
     hipLaunchKernelGGL(kernel, dim3((uint32_t)grid), dim3(block), use_bvh ? bvh_lds : 0, stream, A);
@@ -998,6 +1026,17 @@ int scene_sync(RayzScene* s, RayzRenderStats* stats) {
         }
 #endif
 #ifdef RAYZ_BVH_PROFILE // measurement build only: per-phase wave time and lane occupancy of the BVH kernels
+        if (s->last_bvh && s->last_exchange) {
+            const double wt = (double)(c[4] + c[5] + c[6]), stt = (double)(c[12] + c[13] + c[14]);
+            std::fprintf(stderr, "bvhx walkers (share of wave time): exchange %.1f%% | idle (nobody walks) %.1f%% | rounds %.1f%%; per exchange: %.0f ticks; "
+                                 "at the start of a run of rounds: %.1f lanes walking, %.1f lanes hold a path; runs of rounds %.3g, exchanges %.3g\n",
+                         100.0 * c[4] / wt, 100.0 * c[5] / wt, 100.0 * c[6] / wt, (double)c[4] / (double)(c[7] ? c[7] : 1), (double)c[8] / (double)(c[10] ? c[10] : 1),
+                         (double)c[9] / (double)(c[10] ? c[10] : 1), (double)c[10], (double)c[7]);
+            std::fprintf(stderr, "bvhx shaders (share of wave time): idle, nothing finished %.1f%% | waiting for a batch %.1f%% | pass %.1f%% (%.0f ticks per pass); "
+                                 "%.1f paths per pass, %.1f finished slots seen; passes %.3g\n",
+                         100.0 * c[12] / stt, 100.0 * c[13] / stt, 100.0 * c[14] / stt, (double)c[14] / (double)(c[15] ? c[15] : 1),
+                         (double)c[16] / (double)(c[15] ? c[15] : 1), (double)c[17] / (double)(c[15] ? c[15] : 1), (double)c[15]);
+        } else
         if (s->last_bvh && s->last_two_paths) {
             const double tot = (double)(c[4] + c[5] + c[6] + c[7] + c[8]);
             auto per = [&](int k) { return (double)c[9 + k] / (double)(c[10 + k] ? c[10 + k] : 1); };
@@ -1028,6 +1067,8 @@ int scene_sync(RayzScene* s, RayzRenderStats* stats) {
                          100.0 * (double)c[19] / (double)(c[5] ? c[5] : 1), (double)c[19] / it);
         }
 #endif
+        if (s->last_bvh && c[31] == 2)
+            return fail(RAYZ_ERR_STATE, "the exchange kernel gave up waiting for a hand-over between its waves (bounded wait, no result)");
         if (s->last_bvh && c[31])
             return fail(RAYZ_ERR_STATE, "trace_kernel_bvh refused to run: its dynamic LDS segment does not start at LDS address 0");
         float ms = 0;
@@ -1392,7 +1433,7 @@ int rayz_hip_debug_set(uint32_t knob, long long value) {
             break;
         case RAYZ_DEBUG_BVH_KERNEL:
 #ifdef RAYZ_EXPERIMENTS
-            if (value != 1 && value != 2) return fail(RAYZ_ERR_BAD_ARG, "BVH_KERNEL %lld: 1 or 2", value);
+            if (value < 1 || value > 3) return fail(RAYZ_ERR_BAD_ARG, "BVH_KERNEL %lld: 1, 2 or 3", value);
 #else
             if (value != 1) return fail(RAYZ_ERR_BAD_ARG, "BVH_KERNEL %lld: this build holds the one-path kernel only (the retired two-path "
                                                           "experiment needs -DRAYZ_EXPERIMENTS)", value);
@@ -1407,6 +1448,16 @@ int rayz_hip_debug_set(uint32_t knob, long long value) {
             return fail(RAYZ_ERR_BAD_ARG, "BVH2_KEEP: the two-path kernel is not in this build (-DRAYZ_EXPERIMENTS)");
 #endif
             break;
+        case RAYZ_DEBUG_BVHX: { // slots | exchange threshold << 8 | minimum batch << 16 | patience << 24 | priority << 32
+#ifdef RAYZ_EXPERIMENTS
+            const long long ns = value & 0xff;
+            if (value >> 40 || ns < 4 || ns > 64 || (ns & 1) || !lane_count((value >> 8) & 0xff) || !lane_count((value >> 16) & 0xff))
+                return fail(RAYZ_ERR_BAD_ARG, "BVHX 0x%llx: slots even 4 .. 64, thresholds 1 .. 64 lanes", (unsigned long long)value);
+#else
+            return fail(RAYZ_ERR_BAD_ARG, "BVHX: the exchange kernel is not in this build (-DRAYZ_EXPERIMENTS)");
+#endif
+            break;
+        }
         case RAYZ_DEBUG_LDS_PAD:
             if (value > 160 * 1024) return fail(RAYZ_ERR_BAD_ARG, "LDS_PAD %lld exceeds a CU's LDS", value);
             break;
