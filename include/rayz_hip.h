@@ -29,6 +29,7 @@ extern "C" {
                                    rayz_hip_multi_* (several GPUs behind one call), rayz_hip_kat, chunk_spp auto;
                                    5: rayz_hip_debug_set (the library reads no environment variable),
                                    rayz_hip_multi_device_stats / _timing, RAYZ_GATHER_ALLOW_DUPLICATE_DEVICES */
+#define RAYZ_DEFAULT_TILE_ROWS 8u /* what RayzRenderParams.tile_rows = 0 means (see there) */
 #define RAYZ_MAX_DEVICES 64
 
 typedef enum RayzStatus {
@@ -150,7 +151,12 @@ typedef struct RayzRenderParams {
     uint32_t traversal;      /* RayzTraversal */
     uint32_t chunk_spp;      /* samples summed per work item; 0 = the automatic schedule (rayz_hip_chunk_schedule);
                                 part of the image's definition (fixes the f32 summation tree) */
-    uint32_t tile_rows;      /* rows per shard tile, 0 = 8 */
+    uint32_t tile_rows;      /* rows per shard tile; 0 = RAYZ_DEFAULT_TILE_ROWS (8) in EVERY entry point, single- and multi-device
+                                alike.  Why 8: the BVH kernel deals its work as 8x8 pixel tiles of a shard's LOCAL rows, which are 8
+                                consecutive image rows only with 8-row shard tiles; measured on an 8-way deal (every shard timed on one
+                                GPU, profiles/r04/multi/tile_rows_ab.log): +8.6 % at 1920x1080 (rows 128..136 per rank) and +1.7 % at
+                                3840x2160 against 1-row interleave, whose perfect row balance (135 each) does not make up for tiles
+                                that span 57 image rows.  Irrelevant when shard_count <= 1 */
     uint32_t shard_index;    /* this call renders rows with (row / tile_rows) % shard_count == shard_index */
     uint32_t shard_count;    /* 0 or 1 = whole image */
 } RayzRenderParams;
@@ -253,7 +259,7 @@ int rayz_hip_render_f64(const RayzSceneDesc* scene, const RayzCameraDesc* camera
 /* ---- several GPUs behind ONE call -------------------------------------------------------------------------
  * The reference's caller makes one call, `tracer.render()` (src/rayz.zig:26, src/renderer.zig:72-101).  These
  * entry points give that one call every GPU of the node: the pool is replicated (one scene per device), image
- * rows are dealt to the devices in interleaved tiles of `params->tile_rows` rows (0 = 1: pure row interleave),
+ * rows are dealt to the devices in interleaved tiles of `params->tile_rows` rows (0 = RAYZ_DEFAULT_TILE_ROWS = 8, as everywhere),
  * each device traces its rows on its own stream, and ONE collective — an RCCL gather of the row tiles to
  * devices[0] over xGMI (ncclCommInitAll + ncclGather), or peer copies — reassembles the frame, which is copied
  * to the caller's HOST buffer (height*width*3, row-major RGB).  The image is bit-identical for any device count

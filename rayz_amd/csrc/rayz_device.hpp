@@ -22,6 +22,7 @@
 namespace rayz_dev {
 
 #define RAYZ_CONSTANT __attribute__((address_space(4)))
+#define RAYZ_GLOBAL __attribute__((address_space(1)))
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -143,6 +144,24 @@ __device__ __forceinline__ double ab(double x) { return __builtin_fabs(x); }
 __device__ __forceinline__ uint32_t bits(float x) { return __builtin_bit_cast(uint32_t, x); }
 __device__ __forceinline__ uint32_t bits(double x) { return (uint32_t)__builtin_bit_cast(uint64_t, x); }
 
+// The acceptance rule of every narrow phase: a root in range that is nearer, or as near with the larger hittable
+// index.  Written with & and | on purpose: `&&` / `||` make the compiler branch per term (five s_and_saveexec / s_cbranch_execz
+// pairs around two moves in the candidates' phase); this is four compares, three scalar mask operations and two selects.
+#ifndef RAYZ_BRANCHY_ACCEPT
+template <class R> __device__ __forceinline__ void accept_root(R t, int index, R tmin, R& tbest, int& ibest) {
+    const bool take = (t >= tmin) & ((t < tbest) | ((t == tbest) & (index > ibest)));
+    tbest = take ? t : tbest;
+    ibest = take ? index : ibest;
+}
+#else
+template <class R> __device__ __forceinline__ void accept_root(R t, int index, R tmin, R& tbest, int& ibest) {
+    if (t >= tmin && (t < tbest || (t == tbest && index > ibest))) {
+        tbest = t;
+        ibest = index;
+    }
+}
+#endif
+
 template <class R> struct Bits; // a u32 carried in the bits of an R
 template <> struct Bits<float> {
     static __host__ __device__ __forceinline__ float from(uint32_t u) { return __builtin_bit_cast(float, u); }
@@ -230,8 +249,8 @@ template <class R> __device__ __forceinline__ uint32_t checker_parity(V<R> p, R 
     const uint32_t s = (uint32_t)(int32_t)fx + (uint32_t)(int32_t)fy + (uint32_t)(int32_t)fz;
     return s & 1u;
 }
-template <class R>
-__device__ __forceinline__ V<R> texture_value(const typename VecOf<R>::type* tex, uint32_t idx, V<R> p) { // src/material.zig:19-51
+template <class R, class TexPtr>
+__device__ __forceinline__ V<R> texture_value(TexPtr tex, uint32_t idx, V<R> p) { // src/material.zig:19-51
     typedef typename VecOf<R>::type r4;
     for (int depth = 0; depth < kMaxTextureDepth; ++depth) { // rayz_hip_scene_create refuses deeper chains and cycles
         const r4 h = tex[2 * idx];
@@ -264,10 +283,7 @@ __device__ __forceinline__ void narrow_eval(const d4 c, const d4 v, int pool, V<
         const double rt = __builtin_sqrt(disc2);
         const R t1 = (R)((hb2 - rt) * inv_a2), t2 = (R)((hb2 + rt) * inv_a2);
         const R t = t1 >= tmin ? t1 : t2;
-        if (t >= tmin && (t < tbest || (t == tbest && pool > ibest))) {
-            tbest = t;
-            ibest = pool;
-        }
+        accept_root<R>(t, pool, tmin, tbest, ibest);
     }
 }
 
@@ -350,10 +366,7 @@ __device__ __forceinline__ void tri_accept(R filt, V<R> v0, V<R> e1, V<R> e2, V<
             const V<R> sv{o.x - v0.x, o.y - v0.y, o.z - v0.z};
             const V<R> qv = cross3(sv, e1);
             const R t = dot3(e2, qv) / det;
-            if (t >= tmin && (t < tbest || (t == tbest && prim > ibest))) {
-                tbest = t;
-                ibest = prim;
-            }
+            accept_root<R>(t, prim, tmin, tbest, ibest);
         }
     }
 }
@@ -753,10 +766,15 @@ __device__ __forceinline__ bool shade(const DevScene<R>& sc, Pcg32& g, V<R>& o, 
     typedef typename VecOf<R>::type r4;
     // The pass's three table pointers, read ONCE here: left to itself the compiler re-loads each kernel argument where it is
     // used (scalar registers are short), a scalar load + wait in front of every dependent table fetch of the pass.
-    const r4* pool_p = sc.sph_pool;
-    const r4* mat_p = sc.mat;
-    const r4* tex_p = sc.tex;
-    asm volatile("" : "+s"(pool_p), "+s"(mat_p), "+s"(tex_p));
+    const r4* pool_gen = sc.sph_pool;
+    const r4* mat_gen = sc.mat;
+    const r4* tex_gen = sc.tex;
+    asm volatile("" : "+s"(pool_gen), "+s"(mat_gen), "+s"(tex_gen));
+    // (.. and named GLOBAL again: behind the empty asm the compiler no longer knows the address space and emits flat_load,
+    //  which counts on both wait counters and resolves its aperture per lane)
+    const RAYZ_GLOBAL r4* pool_p = (const RAYZ_GLOBAL r4*)pool_gen;
+    const RAYZ_GLOBAL r4* mat_p = (const RAYZ_GLOBAL r4*)mat_gen;
+    const RAYZ_GLOBAL r4* tex_p = (const RAYZ_GLOBAL r4*)tex_gen;
     if (ibest < 0) {
         const V<R> col = background<R>(ud);
         acc.x = acc.x + thr.x * col.x;
@@ -1429,10 +1447,7 @@ __device__ __forceinline__ void bvh_candidate_eval(BvhQuery<R>& q, const d4 c2, 
         const double rt = __builtin_sqrt(disc2);
         const R t1r = (R)((hb2 - rt) * q.inv_a2), t2r = (R)((hb2 + rt) * q.inv_a2);
         const R t = t1r >= tmin ? t1r : t2r;
-        if (t >= tmin && (t < q.tbest || (t == q.tbest && pool > q.ibest))) {
-            q.tbest = t;
-            q.ibest = pool;
-        }
+        accept_root<R>(t, pool, tmin, q.tbest, q.ibest);
     }
 }
 

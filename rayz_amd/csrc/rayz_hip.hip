@@ -849,7 +849,7 @@ int render_impl(RayzScene* s, const DeviceCtx& ctx, SceneBuffers<R>& b, const Ra
     A.max_bounces = p->max_bounces;
     A.chunk_start = s->chunk_start;
     A.chunks_per_px = chunks_per_px;
-    A.tile_rows = p->tile_rows ? p->tile_rows : 8u;
+    A.tile_rows = p->tile_rows ? p->tile_rows : RAYZ_DEFAULT_TILE_ROWS;
     A.shard_index = p->shard_index;
     A.shard_count = p->shard_count ? p->shard_count : 1u;
     A.shard_pixels = (uint32_t)shard_pixels64;
@@ -1287,7 +1287,7 @@ int multi_render(RayzMulti* m, const RayzCameraDesc* cam, const RayzRenderParams
         return fail(RAYZ_ERR_BAD_ARG, "the multi-device entry shards the frame itself: shard_index / shard_count must be 0");
     const uint32_t n = (uint32_t)m->devices.size();
     RayzRenderParams q = *p;
-    q.tile_rows = p->tile_rows ? p->tile_rows : 1u; // pure row interleave balances best
+    q.tile_rows = p->tile_rows ? p->tile_rows : RAYZ_DEFAULT_TILE_ROWS; // ONE default for every entry point (include/rayz_hip.h)
     q.shard_count = n;
     uint32_t max_rows = 0;
     for (uint32_t i = 0; i < n; ++i) {
@@ -1493,7 +1493,7 @@ void rayz_hip_shutdown(void) {
 
 uint32_t rayz_hip_shard_rows(const RayzRenderParams* p) {
     if (!p) return 0;
-    const uint32_t tr = p->tile_rows ? p->tile_rows : 8u, sc = p->shard_count ? p->shard_count : 1u;
+    const uint32_t tr = p->tile_rows ? p->tile_rows : RAYZ_DEFAULT_TILE_ROWS, sc = p->shard_count ? p->shard_count : 1u;
     if (p->shard_index >= sc) return 0;
     uint32_t n = 0;
     for (uint32_t t = p->shard_index; (uint64_t)t * tr < p->height; t += sc) {

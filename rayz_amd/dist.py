@@ -2,8 +2,9 @@
 
 The path shards embarrassingly (every pixel-sample has its own PCG32 stream keyed by the GLOBAL pixel index,
 so the image does not depend on how rows are dealt out).  Rows go to ranks in interleaved tiles of `tile_rows`
-rows (default 1: pure row interleave — neighbouring rows cost alike, so every rank gets a statistically identical
-1/N of the frame; contiguous bands would be badly balanced, sky rows finish in one segment per sample) and the only
+rows (default 8, the library's own default: the BVH kernel's 8x8 work tiles are then 8 consecutive image rows — measured
++8.6 % / +1.7 % on an 8-way deal of the 1080p / 4K frame against 1-row interleave, profiles/r04/multi/tile_rows_ab.log;
+contiguous bands would be badly balanced, sky rows finish in one segment per sample) and the only
 collective is one all_gather of the ranks' compact row blocks at the end (RCCL over xGMI with backend "nccl";
 the same code runs on gloo for the CPU tests).  The reference has no counterpart: it is single-threaded.
 """
@@ -15,7 +16,7 @@ import torch.distributed as dist
 
 from . import capi, render
 
-DEFAULT_TILE_ROWS = 1
+DEFAULT_TILE_ROWS = 8  # = RAYZ_DEFAULT_TILE_ROWS (include/rayz_hip.h): one default everywhere
 
 
 def shard_params(params: capi.RenderParams, rank: int, world: int, tile_rows: int = DEFAULT_TILE_ROWS) -> capi.RenderParams:
@@ -75,6 +76,15 @@ class FrameGather:
         for r in range(self.world):
             self.frame.index_copy_(0, self._idx[r], parts[r, : len(self.rows[r])])
         return self.frame
+
+
+def frame_sha256(frame: torch.Tensor) -> str:
+    """Fingerprint of a gathered frame: sha256 over its values, row-major RGB, in the frame's own dtype.  The image does not
+    depend on the shard count, so bench.py's N = 1 and N > 1 lines must carry the same value (and the BVH frame the flat
+    list's): a multi-GPU run proves itself."""
+    import hashlib
+
+    return hashlib.sha256(np.ascontiguousarray(frame.detach().cpu().numpy()).tobytes()).hexdigest()
 
 
 def rank_stats(values, device, world: int, group=None) -> np.ndarray:

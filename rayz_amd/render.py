@@ -30,7 +30,7 @@ def shard_rows(params: capi.RenderParams) -> int:
 
 def shard_row_indices(height: int, tile_rows: int, shard_index: int, shard_count: int) -> np.ndarray:
     """Global row numbers of a shard's compact output, in order (host-side bookkeeping of the gather)."""
-    tile_rows = tile_rows or 8
+    tile_rows = tile_rows or 8  # RAYZ_DEFAULT_TILE_ROWS
     shard_count = shard_count or 1
     rows = np.arange(height)
     return rows[(rows // tile_rows) % shard_count == shard_index]

@@ -2,7 +2,9 @@
 //!
 //! SOURCE ONLY: there is no Zig toolchain in the build image, so this file has never been compiled.
 //! The C++ mirror (rayz_amd/host/rayz.hpp `Tracer::render`) performs exactly these steps and is what the
-//! test-suite exercises.  Written against the Zig 0.13/0.14 std the reference uses.
+//! test-suite exercises.  Written against the Zig 0.13/0.14 std the reference uses.  What CAN be checked without a
+//! compiler is checked: tests/test_zig_binding_text.py parses every `extern struct` and `extern "c" fn` below and holds
+//! field names, order and widths, and every prototype's parameter list, to include/rayz_hip.h.
 //!
 //! Usage in the reference tree: copy next to src/renderer.zig, link librayz_hip.so
 //! (`exe.addLibraryPath(...)`, `exe.linkSystemLibrary("rayz_hip")`, `exe.linkLibC()` in build.zig), and
@@ -94,6 +96,14 @@ extern "c" fn rayz_hip_render(
     rgb_out: [*]f32,
     stats: ?*RayzRenderStats,
 ) c_int;
+/// The reference's own arithmetic (f64 path state, roots, hit records and shading: src/vec.zig:4-8): params.precision = 1.
+extern "c" fn rayz_hip_render_f64(
+    scene: *const RayzSceneDesc,
+    camera: *const RayzCameraDesc,
+    params: *const RayzRenderParams,
+    rgb_out: [*]f64,
+    stats: ?*RayzRenderStats,
+) c_int;
 
 /// All GPUs of the node behind the same single call: rows are dealt to `devices` in interleaved tiles, each device
 /// traces its rows, one RCCL gather over xGMI reassembles the frame into `rgb_out` (host, h*w*3).
@@ -104,6 +114,15 @@ extern "c" fn rayz_hip_render_multi(
     camera: *const RayzCameraDesc,
     params: *const RayzRenderParams,
     rgb_out: [*]f32,
+    stats: ?*RayzRenderStats,
+) c_int;
+extern "c" fn rayz_hip_render_multi_f64(
+    devices: [*]const c_int,
+    n_devices: c_int,
+    scene: *const RayzSceneDesc,
+    camera: *const RayzCameraDesc,
+    params: *const RayzRenderParams,
+    rgb_out: [*]f64,
     stats: ?*RayzRenderStats,
 ) c_int;
 
@@ -126,22 +145,37 @@ extern "c" fn rayz_hip_multi_render(
     rgb_out: [*]f32,
     stats: ?*RayzRenderStats,
 ) c_int;
+extern "c" fn rayz_hip_multi_render_f64(
+    multi: *RayzMulti,
+    camera: *const RayzCameraDesc,
+    params: *const RayzRenderParams,
+    rgb_out: [*]f64,
+    stats: ?*RayzRenderStats,
+) c_int;
 extern "c" fn rayz_hip_multi_destroy(multi: ?*RayzMulti) c_int;
 
 fn v3(v: vec.V3) [3]f64 {
     return .{ v.x, v.y, v.z };
 }
 
+pub const Precision = enum(u32) { f32 = 0, f64 = 1 }; // RayzPrecision
+pub const Traversal = enum(u32) { flat_list = 0, bvh = 1, auto = 2 }; // RayzTraversal
+
 pub const HipOptions = struct {
     seed: ?u64 = null, // null: next u64 of the Tracer's own DefaultPrng
-    tmin: f64 = 1e-3,
+    // .f32: f32 path state and reject tests, f64 candidate roots, tmin 1e-3 (the fast default).  .f64: the reference's own scalar
+    // type for path state, roots, hit records and shading (src/vec.zig:4-8) with its tmin of 1e-10 (src/renderer.zig:107);
+    // the frame is written straight into img.pixels (f64, src/image.zig:4-17) without narrowing.
+    precision: Precision = .f32,
+    traversal: Traversal = .auto, // the reference always walks its BVH (src/renderer.zig:76-78, src/hit.zig:181-216)
+    tmin: ?f64 = null, // null: 1e-3 for .f32, 1e-10 for .f64
     devices: []const c_int = &.{}, // empty: device 0; e.g. &.{ 0, 1, 2, 3, 4, 5, 6, 7 } for a whole MI355X node
     // in/out: a handle kept across frames for `devices` (null: created by the first renderHip call that has devices;
     // the caller releases it with rayz_hip_multi_destroy).  The pool must not change while it is kept.
     multi: ?*?*RayzMulti = null,
 };
 
-/// The body of `Tracer.render()`: flatten → one extern call → widen f32 → f64 into img.pixels.
+/// The body of `Tracer.render()`: flatten → one extern call → the frame into img.pixels (f32 widened, or f64 as it is).
 pub fn renderHip(self: *renderer.Tracer, opt: HipOptions) !usize {
     const a = self.allocator;
     // Zig structs / unions have no defined layout: copy field by field (SURVEY.md §8b "Layout caveat").
@@ -189,11 +223,35 @@ pub fn renderHip(self: *renderer.Tracer, opt: HipOptions) !usize {
         .samples_per_px = @intCast(self.samples_per_px),
         .max_bounces = @intCast(self.max_bounces),
         .seed = opt.seed orelse self.rng.random().int(u64),
-        .tmin = opt.tmin,
+        .tmin = opt.tmin orelse (if (opt.precision == .f64) @as(f64, 1e-10) else @as(f64, 1e-3)),
+        .precision = @intFromEnum(opt.precision),
+        .traversal = @intFromEnum(opt.traversal),
     };
-    const rgb = try a.alloc(f32, self.img.w * self.img.h * 3);
-    defer a.free(rgb);
     var stats: RayzRenderStats = undefined;
+    const n_px = self.img.w * self.img.h;
+    if (opt.precision == .f64) {
+        // the reference's arithmetic: an f64 frame, copied field by field into img.pixels (V3 is a plain Zig struct: no
+        // defined layout, so the library cannot write into it directly)
+        const rgb = try a.alloc(f64, n_px * 3);
+        defer a.free(rgb);
+        const rc = if (opt.devices.len == 0)
+            (if (rayz_hip_init(0) != 0) @as(c_int, -4) else rayz_hip_render_f64(&scene, &cam, &params, rgb.ptr, &stats))
+        else if (opt.multi) |slot| blk: {
+            if (slot.* == null) {
+                const crc = rayz_hip_multi_create(opt.devices.ptr, @intCast(opt.devices.len), &scene, 0, slot);
+                if (crc != 0) break :blk crc;
+            }
+            break :blk rayz_hip_multi_render_f64(slot.*.?, &cam, &params, rgb.ptr, &stats);
+        } else rayz_hip_render_multi_f64(opt.devices.ptr, @intCast(opt.devices.len), &scene, &cam, &params, rgb.ptr, &stats);
+        if (rc != 0) {
+            std.debug.print("rayz_hip: {s}\n", .{rayz_hip_last_error()});
+            return error.GpuRenderFailed;
+        }
+        for (self.img.pixels, 0..) |*px, i| px.* = .{ .x = rgb[3 * i], .y = rgb[3 * i + 1], .z = rgb[3 * i + 2] };
+        return @intCast(stats.primary_rays);
+    }
+    const rgb = try a.alloc(f32, n_px * 3);
+    defer a.free(rgb);
     const rc = if (opt.devices.len == 0)
         (if (rayz_hip_init(0) != 0) @as(c_int, -4) else rayz_hip_render(&scene, &cam, &params, rgb.ptr, &stats))
     else if (opt.multi) |slot| blk: {
@@ -207,6 +265,6 @@ pub fn renderHip(self: *renderer.Tracer, opt: HipOptions) !usize {
         std.debug.print("rayz_hip: {s}\n", .{rayz_hip_last_error()});
         return error.GpuRenderFailed;
     }
-    for (self.img.pixels, 0..) |*px, i| px.* = .{ .x = rgb[3 * i], .y = rgb[3 * i + 1], .z = rgb[3 * i + 2] };
+    for (self.img.pixels, 0..) |*px, i| px.* = .{ .x = rgb[3 * i], .y = rgb[3 * i + 1], .z = rgb[3 * i + 2] }; // widen f32 -> f64
     return @intCast(stats.primary_rays); // what render() returns, src/renderer.zig:90,100
 }

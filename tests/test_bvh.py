@@ -205,6 +205,31 @@ def test_gpu_bvh_parity_10k_and_equals_flat_list(gpu, oracle):
 
 
 @pytest.mark.gpu
+def test_lds_request_falls_back_to_a_shorter_top(gpu, oracle):
+    """render_impl sizes the tree's LDS top for a 150 KB workgroup; a stack that refuses the request must not fail every BVH
+    render: the launch retries with a shorter prefix of the top (the walk reads the rest from global memory).  Forced here with
+    RAYZ_DEBUG_LDS_PAD (unused bytes added to the request): same image as the oracle, a pad no retry can absorb is an error."""
+    from rayz_amd import render
+
+    t = tracer.randomBouncing(96, -20, 20, seed=42)
+    t.samples_per_px, t.max_bounces = 4, 10
+    t.set_gpu(render_seed=9, traversal=capi.TRAVERSAL_BVH)
+    scene, cam, p = t.scene_desc(), t.camera_desc(), t.params()
+    want, ost = oracle.render_b(scene, cam, p)
+    try:
+        for pad in (0, 8 * 1024, 40 * 1024, 70 * 1024):
+            render.debug_set(capi.DEBUG_LDS_PAD, pad)
+            got, gst = gpu.render_host(scene, cam, p)
+            assert_images_equal(got, want, f"LDS pad {pad}")
+            assert gst.segments == ost.segments
+        render.debug_set(capi.DEBUG_LDS_PAD, 159 * 1024)  # more than a CU has beside the stacks, whatever the top
+        with pytest.raises(capi.RayzHipError, match="LDS"):
+            gpu.render_host(scene, cam, p)
+    finally:
+        render.debug_set(capi.DEBUG_LDS_PAD, -1)
+
+
+@pytest.mark.gpu
 def test_gpu_bvh_equals_flat_list_on_the_whole_config3_frame(gpu):
     """1920x1080, 10,003 spheres, 16 spp = 33 M paths, ≈1e8 segments through both traversals on the device: identical
     images, identical segment counts."""
@@ -230,6 +255,33 @@ def test_gpu_bvh_equals_flat_list_at_baseline_config3_in_full(gpu):
     flat, fst = gpu.render_host(t.scene_desc(), t.camera_desc(), t.params())
     assert np.array_equal(bvh, flat) and bst.segments == fst.segments and np.isfinite(flat).all()
     assert fst.primary_rays == 1920 * 1080 * 1024 and 2.9 < fst.segments / fst.primary_rays < 3.0
+
+
+@pytest.mark.gpu
+def test_baseline_config2_in_full(gpu, oracle):
+    """BASELINE.json configs[1] exactly as bench.py measures it — `randomBouncing` as the reference ships it (src/rayz.zig:45-168:
+    485 spheres, scene seed 42), 1920x1080, 256 spp, 50 bounces, render seed 1: the flat list and the BVH on the device give the
+    same image bit for bit and the same segment count; 48 scattered pixels rendered by the oracle at the full 256 spp match bit for
+    bit; the frame is a usable image.  (The only BASELINE config the suite used to run in miniature only.)"""
+    t = tracer.randomBouncing(1920, seed=42)
+    assert (t.info().width, t.info().height, t.info().n_spheres) == (1920, 1080, 485)
+    t.samples_per_px, t.max_bounces = 256, 50
+    t.set_gpu(render_seed=1, traversal=capi.TRAVERSAL_BVH)
+    scene, cam, p = t.scene_desc(), t.camera_desc(), t.params()
+    bvh, bst = gpu.render_host(scene, cam, p)
+    t.set_gpu(traversal=capi.TRAVERSAL_LINEAR)
+    pf = t.params()
+    flat, fst = gpu.render_host(scene, cam, pf)
+    assert np.array_equal(bvh, flat) and bst.segments == fst.segments
+    assert flat.shape == (1080, 1920, 3) and np.isfinite(flat).all() and (flat >= 0).all()
+    assert fst.primary_rays == 1920 * 1080 * 256 and 2.6 < fst.segments / fst.primary_rays < 2.9
+    rng = np.random.default_rng(2)
+    pix = np.unique(np.concatenate([rng.integers(0, 1920 * 1080, 44), [0, 1919, 1920 * 1079, 1920 * 1080 - 1]])).astype(np.uint32)
+    want, _ = oracle.render_b(scene, cam, pf, pixels=pix)
+    assert_images_equal(flat.reshape(-1, 3)[pix], want, "config 2 at full size, oracle spot pixels")
+    t.set_gpu(traversal=capi.TRAVERSAL_AUTO)  # what Tracer.render() uses: the BVH for this scene (485 > 160 hittables)
+    auto, ast = gpu.render_host(scene, cam, t.params())
+    assert np.array_equal(auto, flat) and ast.node_tests > 0
 
 
 @pytest.mark.gpu

@@ -1,6 +1,7 @@
 """The N > 1 path on CPU: two gloo ranks shard a frame by interleaved row tiles, each "renders" its rows (with
 the oracle standing in for the GPU, test-side only), one all_gather reassembles the frame, and the result is
-identical to the unsharded image.  Exercises rayz_amd/dist.py exactly as bench.py uses it."""
+identical to the unsharded image — and hashes to the same `frame_sha256` bench.py prints for N = 1.  Exercises
+rayz_amd/dist.py exactly as bench.py uses it."""
 import os
 import sys
 
@@ -71,14 +72,22 @@ def _worker(rank, world, port, tile_rows, q):
         t.samples_per_px, t.max_bounces = 3, 6
         t.set_gpu(render_seed=8)
         sd, cam, p = t.scene_desc(), t.camera_desc(), t.params()
-        fg = rdist.FrameGather(p.height, p.width, world, rank, torch.device("cpu"), tile_rows=tile_rows)
-        mine, _ = oracle.render_b(sd, cam, rdist.shard_params(p, rank, world, tile_rows), threads=1)
+        if tile_rows == 0:  # the default deal, exactly as bench.py makes it
+            fg = rdist.FrameGather(p.height, p.width, world, rank, torch.device("cpu"))
+            mine, _ = oracle.render_b(sd, cam, rdist.shard_params(p, rank, world), threads=1)
+        else:
+            fg = rdist.FrameGather(p.height, p.width, world, rank, torch.device("cpu"), tile_rows=tile_rows)
+            mine, _ = oracle.render_b(sd, cam, rdist.shard_params(p, rank, world, tile_rows), threads=1)
         assert mine.shape[0] == len(fg.my_rows)
         fg.tile[: mine.shape[0]] = torch.from_numpy(mine)
-        frame = fg.gather().numpy().copy()
+        frame_t = fg.gather()
+        sha = rdist.frame_sha256(frame_t)  # what bench.py prints as `frame_sha256`
+        frame = frame_t.numpy().copy()
         if rank == 0:
             full, _ = oracle.render_b(sd, cam, p, threads=1)
-            q.put(bool(np.array_equal(frame, full)))
+            one = rdist.FrameGather(p.height, p.width, 1, 0, torch.device("cpu"))  # the N = 1 line's frame
+            one.tile.copy_(torch.from_numpy(full))
+            q.put(bool(np.array_equal(frame, full)) and sha == rdist.frame_sha256(one.gather()) and len(sha) == 64)
         # the per-rank figures of bench.py's N > 1 line: every rank gets every rank's row
         table = rdist.rank_stats([10.0 + rank, 0.5 * (rank + 1), 1000.0 * (rank + 1)], torch.device("cpu"), world)
         assert table.shape == (world, 3) and table[:, 0].tolist() == [10.0 + r for r in range(world)]
@@ -94,7 +103,7 @@ def _worker(rank, world, port, tile_rows, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,tile_rows", [(2, 1), (2, 8), (3, 4)])
+@pytest.mark.parametrize("world,tile_rows", [(2, 0), (2, 1), (2, 8), (3, 4), (3, 0)])  # 0 = the default deal (8-row tiles)
 def test_row_tile_shard_and_gather_gloo(built, world, tile_rows):
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
@@ -109,5 +118,6 @@ def test_frame_gather_single_rank(built):
     fg = rdist.FrameGather(10, 4, 1, 0, torch.device("cpu"))
     fg.tile.copy_(torch.arange(10 * 4 * 3, dtype=torch.float32).reshape(10, 4, 3))
     assert torch.equal(fg.gather(), fg.tile)
-    assert rdist.max_shard_rows(1080, 8) == 135 and rdist.max_shard_rows(2160, 8) == 270
-    assert rdist.max_shard_rows(1080, 8, tile_rows=8) == 136
+    assert rdist.DEFAULT_TILE_ROWS == 8  # = RAYZ_DEFAULT_TILE_ROWS, the library's one default (include/rayz_hip.h)
+    assert rdist.max_shard_rows(1080, 8) == 136 and rdist.max_shard_rows(2160, 8) == 272
+    assert rdist.max_shard_rows(1080, 8, tile_rows=1) == 135

@@ -67,7 +67,8 @@ def test_multi_n_way_on_one_device(gpu, oracle, n, tile_rows):
         # per-device counters: every shard's own rows / segments / kernel time; they add up to the frame's
         per = m.device_stats()
         assert len(per) == n and sum(d.primary_rays for d in per) == st.primary_rays
-        assert sum(d.segments for d in per) == st.segments and all(d.kernel_ms > 0 for d in per)
+        # (a device the deal leaves without rows — 8-row tiles of a small frame on 8 devices — launches nothing)
+        assert sum(d.segments for d in per) == st.segments and all((d.kernel_ms > 0) == (d.primary_rays > 0) for d in per)
         assert max(d.kernel_ms for d in per) == st.kernel_ms
         gather_ms, frame_ms = m.timing()
         assert 0 < gather_ms < 1e4 and frame_ms >= gather_ms * 0.5

@@ -8,6 +8,9 @@ B="python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-also"
 run() { name=$1; shift; echo "== $name: $*"; timeout -k 5 400 rocprofv3 "$@" --output-format csv -d $out/$name -o $name -- $B --steps 1 --warmup 0 > $out/$name.log 2>&1; echo "$name rc=$?"; }
 echo "== stats"; timeout -k 5 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o stats -- $B --steps 2 --warmup 1 > $out/stats.log 2>&1; echo "stats rc=$?"; grep -h "^{" $out/stats.log > $out/stats_bench_line.json
 run pmc_fetch --pmc FETCH_SIZE
+run pmc_fetch2 --pmc FETCH_SIZE   # (bimodal from launch to launch: taken four times, the summary keeps the largest and lists all)
+run pmc_fetch3 --pmc FETCH_SIZE
+run pmc_fetch4 --pmc FETCH_SIZE
 run pmc_write --pmc WRITE_SIZE
 run pmc_sq --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_THREAD_CYCLES_VALU SQ_INSTS_LDS
 run pmc_l2 --pmc GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum SQ_WAIT_ANY SQ_WAIT_INST_ANY
