@@ -157,7 +157,12 @@ typedef struct RayzRenderParams {
                                 GPU, profiles/r04/multi/tile_rows_ab.log): +8.6 % at 1920x1080 (rows 128..136 per rank) and +1.7 % at
                                 3840x2160 against 1-row interleave, whose perfect row balance (135 each) does not make up for tiles
                                 that span 57 image rows.  Irrelevant when shard_count <= 1 */
-    uint32_t shard_index;    /* this call renders rows with (row / tile_rows) % shard_count == shard_index */
+    uint32_t shard_index;    /* this call renders the rows of the tiles (tile = row / tile_rows) this shard owns in the SERPENTINE deal: the
+                                tiles are taken in bands of shard_count; in even bands tile position p goes to shard p, in odd bands to
+                                shard shard_count - 1 - p (0 1 .. N-1, N-1 .. 1 0, 0 1 ..).  A plain round-robin gives shard N-1 rows that lie
+                                (N-1) * tile_rows further down the frame than shard 0's in EVERY band, and cost grows down the frame (sky above,
+                                ground below): measured 9 % between the lightest and the heaviest of 8 shards of the 1080p frame; alternating
+                                the direction cancels that trend (profiles/r04/multi/).  The output is the shard's rows in frame order */
     uint32_t shard_count;    /* 0 or 1 = whole image */
 } RayzRenderParams;
 
@@ -203,7 +208,9 @@ typedef enum RayzDebugKnob {
     RAYZ_DEBUG_BVH_SPLIT = 9,     /* how trees built from now on split a node: 0 = surface-area heuristic (default), 1 = the reference's median split */
     RAYZ_DEBUG_BVHX = 10,         /* exchange kernel (RAYZ_DEBUG_BVH_KERNEL = 3, -DRAYZ_EXPERIMENTS builds only): slots per walker wave | exchange threshold << 8 |
                                      shader's minimum batch << 16 | its patience << 24 | its priority << 32 */
-    RAYZ_DEBUG_KNOBS = 11
+    RAYZ_DEBUG_CHUNK_CAP = 11,    /* -DRAYZ_EXPERIMENTS builds only, refused otherwise — it CHANGES the image's summation tree (the one knob that
+                                     does; tools/chunk_cap_sweep.py): largest chunk of the automatic schedule */
+    RAYZ_DEBUG_KNOBS = 12
 } RayzDebugKnob;
 int rayz_hip_debug_set(uint32_t knob, long long value);
 

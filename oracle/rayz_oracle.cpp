@@ -1188,6 +1188,18 @@ static PathResult<R> tracePath(const SceneB<R>& sc, const CamB<R>& cam, const Ra
 }
 
 // Chunk schedule, restated: which consecutive samples of a pixel are summed by one work item.
+// Largest chunk of the automatic schedule: pixels · spp / 2^24 held to [64, 256], a power of two, at most
+// spp / 2 — no work item larger than 1/8 of a lane's share when the frame is dealt to 8 GPUs of 2^18 lanes.
+static u32 autoChunk(u64 pixels, u32 spp) {
+    u64 share = pixels >= (1ull << 32) ? 256 : (pixels * spp) >> 24;
+    if (share < 64) share = 64;
+    if (share > 256) share = 256;
+    u32 c = 1;
+    while (2 * (u64)c <= share) c *= 2;
+    u32 half = 1;
+    while (2 * (u64)half <= spp / 2) half *= 2;
+    return c < half ? c : half;
+}
 static std::vector<u32> chunkSchedule(const RayzRenderParams& p) {
     std::vector<u32> st{0};
     const u32 spp = p.samples_per_px;
@@ -1202,8 +1214,7 @@ static std::vector<u32> chunkSchedule(const RayzRenderParams& p) {
         while (2 * (u64)r <= v) r *= 2;
         return r;
     };
-    u32 C = pow2floor(spp / 2);
-    if (C > 256) C = 256;
+    u32 C = autoChunk((u64)p.width * p.height, spp);
     u32 at = 0, rem = spp;
     while (rem >= 2 * C) {
         at += C, rem -= C;
@@ -1223,11 +1234,13 @@ static inline u32 shardRows(const RayzRenderParams& p, std::vector<u32>* rows) {
     const u32 tr = p.tile_rows ? p.tile_rows : 8;
     const u32 sc = p.shard_count ? p.shard_count : 1;
     u32 n = 0;
-    for (u32 r = 0; r < p.height; ++r)
-        if ((r / tr) % sc == p.shard_index) {
+    for (u32 r = 0; r < p.height; ++r) { // the serpentine deal (include/rayz_hip.h: RayzRenderParams.shard_index)
+        const u32 tile = r / tr, band = tile / sc, pos = tile % sc;
+        if (((band & 1) ? sc - 1 - pos : pos) == p.shard_index) {
             if (rows) rows->push_back(r);
             ++n;
         }
+    }
     return n;
 }
 
@@ -1243,8 +1256,7 @@ static int render(const RayzSceneDesc* sd, const RayzCameraDesc* cd, const RayzR
         const u64 c = p.chunk_spp ? p.chunk_spp : 16;
         u64 n = (spp + c - 1) / c;
         if (!uniform) { // the automatic schedule's length, exactly: full chunks of C while 2C remain, then the halving tail
-            u64 C = 1;
-            while (C <= spp / 4 && C < 256) C *= 2;
+            const u64 C = autoChunk((u64)p.width * p.height, (u32)spp);
             n = 0;
             u64 rem = spp;
             if (rem >= 2 * C) n = (rem - 2 * C) / C + 1, rem -= n * C;

@@ -17,7 +17,7 @@ MAX_DEVICES = 64
 GATHER_RCCL, GATHER_PEER_COPY = 0, 1
 GATHER_ALLOW_DUPLICATE_DEVICES = 0x100  # flag bit, peer-copy only (tests on a one-GPU box)
 (DEBUG_QUEUE_GRAB, DEBUG_BVH_KEEP, DEBUG_BVH_PEEL, DEBUG_BVH_TOP, DEBUG_BVH_KERNEL, DEBUG_BVH2_KEEP,
- DEBUG_LDS_PAD, DEBUG_BVH_TOP_ORDER, DEBUG_BVH_NODES, DEBUG_BVH_SPLIT, DEBUG_BVHX) = range(11)
+ DEBUG_LDS_PAD, DEBUG_BVH_TOP_ORDER, DEBUG_BVH_NODES, DEBUG_BVH_SPLIT, DEBUG_BVHX, DEBUG_CHUNK_CAP) = range(12)
 (KAT_REFRACT, KAT_REFLECTANCE, KAT_GET_RAY, KAT_BOX_HIT, KAT_SPHERE_HIT, KAT_SCATTER, KAT_CHECKER, KAT_BACKGROUND,
  KAT_TRIANGLE_HIT, KAT_SCAN_DISCS) = range(10)
 KAT_IN_STRIDE, KAT_OUT_STRIDE = 48, 12

@@ -118,6 +118,7 @@ template <class R> struct TraceArgs {
     uint32_t width, height, spp, max_bounces;
     const uint32_t* chunk_start; // [chunks_per_px + 1] first sample of every chunk of a pixel (the chunk schedule)
     uint32_t chunks_per_px;
+    uint32_t chunk_uniform, chunk_n_uniform; // the table's uniform prefix: chunk k < chunk_n_uniform covers samples k·chunk_uniform .. (k+1)·chunk_uniform
     uint32_t tile_rows, shard_index, shard_count, shard_pixels;
     uint32_t tiled_pixels;   // the first this-many local pixels are dealt to the queue as 8x8 tiles (place_item)
     uint32_t total_items;
@@ -851,6 +852,20 @@ template <class R> __device__ __forceinline__ void path_init(PathState<R>& p) {
     p.item = p.px = p.py = p.s_cur = p.s_end = p.seg = 0;
     p.has_item = p.alive = false;
 }
+// Samples of chunk k (the chunk schedule).  Every schedule starts with a run of equal chunks — all of it for a
+// uniform one, all but the halving tail for the automatic one — and the host hands over that run's size and length: a lane
+// that pops an item of the run computes its bounds; only the tail's few items read the table (two dependent loads in the
+// refill of a pass whenever some lane pops — with 32-sample chunks that is every second pass).
+template <class R> __device__ __forceinline__ void chunk_bounds(const TraceArgs<R>& A, uint32_t k, uint32_t& s0, uint32_t& s1) {
+    if (k < A.chunk_n_uniform) {
+        s0 = k * A.chunk_uniform;
+        s1 = s0 + A.chunk_uniform;
+    } else {
+        s0 = A.chunk_start[k];
+        s1 = A.chunk_start[k + 1];
+    }
+}
+
 // ---- the work queue, as a wave sees it ------------------------------------------------------------------------
 // Items come off one global counter.  A wave does not pay an atomic per refill (one word takes ≈88 atomics per µs on this
 // chip: with the short items of a small scene the queue head, not the tracing, set the pace — 100 spheres ran at 3.8
@@ -874,7 +889,10 @@ template <class R, bool kTiled> __device__ __forceinline__ uint32_t place_item(c
     const uint32_t lr = lp / A.width;
     px = lp - lr * A.width;
     const uint32_t tl = lr / A.tile_rows, within = lr - tl * A.tile_rows;
-    py = (tl * A.shard_count + A.shard_index) * A.tile_rows + within;
+    // (the serpentine deal of include/rayz_hip.h: this shard's tile of band tl sits at position shard_index, or — odd bands —
+    //  shard_count - 1 - shard_index)
+    const uint32_t pos = (tl & 1u) ? A.shard_count - 1u - A.shard_index : A.shard_index;
+    py = (tl * A.shard_count + pos) * A.tile_rows + within;
     return k;
 }
 
@@ -928,8 +946,7 @@ __device__ __forceinline__ void path_refill(PathState<R>& p, const TraceArgs<R>&
             p.item = got_item;
             p.has_item = true;
             const uint32_t k = place_item<R, false>(A, p.item, p.px, p.py);
-            p.s_cur = A.chunk_start[k];
-            p.s_end = A.chunk_start[k + 1];
+            chunk_bounds<R>(A, k, p.s_cur, p.s_end);
             p.acc = {R(0), R(0), R(0)};
         }
     }
@@ -1555,8 +1572,7 @@ void trace_kernel_bvh(const TraceArgs<R> A) {
                 item = got_item;
                 has_item = true;
                 const uint32_t k = place_item<R, true>(A, item, px, py);
-                s_cur = A.chunk_start[k];
-                s_end = A.chunk_start[k + 1];
+                chunk_bounds<R>(A, k, s_cur, s_end);
                 acc = {R(0), R(0), R(0)};
             }
             // the per-lane u32 statistics would wrap after ≈30 minutes inside one launch: spill them when half full
@@ -1853,8 +1869,7 @@ template <class R, bool QUANT> __global__ __launch_bounds__(256, RAYZ_BVH2_WAVES
                     c.item = got_item;
                     c.has_item = true;
                     const uint32_t k = place_item<R, true>(A, c.item, c.px, c.py);
-                    c.s_cur = A.chunk_start[k];
-                    c.s_end = A.chunk_start[k + 1];
+                    chunk_bounds<R>(A, k, c.s_cur, c.s_end);
                     c.acc = {R(0), R(0), R(0)};
                 }
                 if (popping && node_tests > RAYZ_STAT_SPILL) { // (see trace_kernel_bvh)
@@ -2362,8 +2377,7 @@ template <bool QUANT> __global__ __launch_bounds__(1024, 1) void trace_kernel_bv
                     item = got_item;
                     has_item = true;
                     const uint32_t k = place_item<R, true>(A, item, px, py);
-                    s_cur = A.chunk_start[k];
-                    s_end = A.chunk_start[k + 1];
+                    chunk_bounds<float>(A, k, s_cur, s_end);
                     acc = {R(0), R(0), R(0)};
                 }
                 if (popping && nseg > RAYZ_STAT_SPILL) {

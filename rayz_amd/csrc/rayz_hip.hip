@@ -163,12 +163,29 @@ uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
 
 // ---- chunk schedule: which samples of a pixel are summed together ------------------------------
 // params.chunk_spp != 0: uniform chunks of that many samples (the last one shorter).  0 = automatic: frames of fewer
-// than 2^19 pixels, or fewer than 64 samples per pixel, use uniform chunks of 16; larger renders use chunks of
-// C = min(256, largest power of two <= spp / 2) while at least 2 C samples remain, and split the rest by halving down
-// to 16 (.. C, C/2, C/4, .., 16, 16): few partial sums per pixel (8 for 1024 spp instead of 64), and the work queue —
-// which hands out chunk 0 of every pixel, then chunk 1, .. — ends in SHORT items, so no lane is left with a long
-// item while the others have run dry.  Depends on the full frame's size, never on the shard: the image is the same
-// for every GPU count.
+// than 2^19 pixels, or fewer than 64 samples per pixel, use uniform chunks of 16; larger renders use chunks of C samples
+// while at least 2 C remain, and split the rest by halving down to 16 (.. C, C/2, C/4, .., 16, 16): the work queue — which
+// hands out chunk 0 of every pixel, then chunk 1, .. — ends in SHORT items, so no lane is left with a long item while the
+// others have run dry.  C (auto_chunk) is sized for the frame being DEALT TO 8 GPUs (round 4): no work item larger than 1/8
+// of what a lane of a 2^18-lane GPU gets of an 8-way deal, C = pixels · spp / 2^24 held to [64, 256] (a power of two, at most
+// spp / 2) — 64 for 1920x1080x1024, 256 for 3840x2160x4096.  Measured (profiles/r04/multi/): with C = 256 one GPU's share of
+// the 1080p frame runs at 80 - 87 % of the whole-frame rate (≈1 pixel per lane: three items of a quarter of a lane's work
+// each, nothing left to balance with), with 64 at 94 %; the whole frame on ONE GPU changes by +1.0 % (flat list) / −1.2 % (BVH).
+// The price is partial sums: 18 per pixel instead of 8 at 1024 spp.  Depends on the full frame's size, never on the shard or
+// the GPU count: the image is the same for every deal.
+uint32_t auto_chunk(uint64_t pixels, uint32_t spp) {
+    auto pow2floor = [](uint64_t v) {
+        uint64_t r = 1;
+        while (r <= v / 2) r *= 2;
+        return r;
+    };
+    const uint64_t share = pixels >= (1ull << 32) ? 256 : (pixels * spp) >> 24;
+    long long cap = (long long)pow2floor(std::min<uint64_t>(256, std::max<uint64_t>(64, share)));
+#ifdef RAYZ_EXPERIMENTS // tools/chunk_cap_sweep.py only: CHANGES the summation tree (the oracle does not follow it)
+    cap = tuning(RAYZ_DEBUG_CHUNK_CAP, cap);
+#endif
+    return (uint32_t)std::min<uint64_t>((uint64_t)cap, pow2floor(spp / 2));
+}
 void chunk_schedule(const RayzRenderParams* p, std::vector<uint32_t>& starts) {
     const uint32_t spp = p->samples_per_px;
     starts.clear();
@@ -185,7 +202,7 @@ void chunk_schedule(const RayzRenderParams* p, std::vector<uint32_t>& starts) {
         while (r <= v / 2) r *= 2;
         return r;
     };
-    const uint32_t C = std::min(256u, pow2floor(spp / 2));
+    const uint32_t C = auto_chunk((uint64_t)p->width * p->height, spp);
     uint32_t at = 0, rem = spp;
     while (rem >= 2 * C) at += C, rem -= C, starts.push_back(at);
     while (rem > 16) {
@@ -212,7 +229,7 @@ uint64_t chunk_count(const RayzRenderParams* p) {
         while (r <= v / 2) r *= 2;
         return r;
     };
-    const uint64_t C = std::min<uint64_t>(256, pow2floor(spp / 2));
+    const uint64_t C = auto_chunk((uint64_t)p->width * p->height, (uint32_t)spp);
     uint64_t n = spp >= 2 * C ? (spp - 2 * C) / C + 1 : 0, rem = spp - n * C;
     while (rem > 16) rem -= std::max<uint64_t>(16, pow2floor(rem / 2)), ++n;
     return n + (rem ? 1 : 0);
@@ -849,6 +866,9 @@ int render_impl(RayzScene* s, const DeviceCtx& ctx, SceneBuffers<R>& b, const Ra
     A.max_bounces = p->max_bounces;
     A.chunk_start = s->chunk_start;
     A.chunks_per_px = chunks_per_px;
+    A.chunk_uniform = starts[1]; // the table's uniform prefix (chunk_bounds): chunks of starts[1] samples while the table keeps that stride
+    A.chunk_n_uniform = 0;
+    while (A.chunk_n_uniform < chunks_per_px && starts[A.chunk_n_uniform + 1] == (A.chunk_n_uniform + 1) * A.chunk_uniform) A.chunk_n_uniform++;
     A.tile_rows = p->tile_rows ? p->tile_rows : RAYZ_DEFAULT_TILE_ROWS;
     A.shard_index = p->shard_index;
     A.shard_count = p->shard_count ? p->shard_count : 1u;
@@ -1200,7 +1220,8 @@ __global__ __launch_bounds__(256) void unshard_kernel(const T* __restrict__ gath
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)height * row_elems) return;
     const uint32_t y = (uint32_t)(i / row_elems), x = (uint32_t)(i - (size_t)y * row_elems);
-    const uint32_t tile = y / tile_rows, rank = tile % n_ranks, local = (tile / n_ranks) * tile_rows + (y - tile * tile_rows);
+    const uint32_t tile = y / tile_rows, band = tile / n_ranks, pos = tile - band * n_ranks;
+    const uint32_t rank = (band & 1u) ? n_ranks - 1u - pos : pos, local = band * tile_rows + (y - tile * tile_rows); // the serpentine deal
     frame[i] = gathered[((size_t)rank * max_rows + local) * row_elems + x];
 }
 
@@ -1458,6 +1479,13 @@ int rayz_hip_debug_set(uint32_t knob, long long value) {
 #endif
             break;
         }
+        case RAYZ_DEBUG_CHUNK_CAP:
+#ifdef RAYZ_EXPERIMENTS
+            if (value < 16 || value > 4096 || (value & (value - 1))) return fail(RAYZ_ERR_BAD_ARG, "CHUNK_CAP %lld: a power of two, 16 .. 4096", value);
+#else
+            return fail(RAYZ_ERR_BAD_ARG, "CHUNK_CAP changes the image's summation tree: -DRAYZ_EXPERIMENTS builds only");
+#endif
+            break;
         case RAYZ_DEBUG_LDS_PAD:
             if (value > 160 * 1024) return fail(RAYZ_ERR_BAD_ARG, "LDS_PAD %lld exceeds a CU's LDS", value);
             break;
@@ -1496,8 +1524,11 @@ uint32_t rayz_hip_shard_rows(const RayzRenderParams* p) {
     const uint32_t tr = p->tile_rows ? p->tile_rows : RAYZ_DEFAULT_TILE_ROWS, sc = p->shard_count ? p->shard_count : 1u;
     if (p->shard_index >= sc) return 0;
     uint32_t n = 0;
-    for (uint32_t t = p->shard_index; (uint64_t)t * tr < p->height; t += sc) {
-        const uint32_t r0 = t * tr;
+    for (uint64_t band = 0;; ++band) { // one tile per band of shard_count tiles, at alternating positions (the serpentine deal)
+        const uint64_t t = band * sc + ((band & 1) ? sc - 1 - p->shard_index : p->shard_index);
+        if (band * sc * tr >= p->height) break;
+        if (t * tr >= p->height) continue; // (this band is the frame's last, partial one and ends before this shard's tile)
+        const uint32_t r0 = (uint32_t)(t * tr);
         n += (p->height - r0 < tr) ? p->height - r0 : tr;
     }
     return n;

@@ -255,9 +255,12 @@ def test_chunk_schedule_properties_and_oracle_agreement(built, oracle):
             assert sched(lib.rayz_hip_chunk_schedule, **kw, shard_count=sc, shard_index=1, tile_rows=1) == a
     assert sched(lib.rayz_hip_chunk_schedule, width=64, height=36, samples_per_px=40) == [0, 16, 32, 40]
     big = sched(lib.rayz_hip_chunk_schedule, width=1920, height=1080, samples_per_px=1024)
-    assert [y - x for x, y in zip(big, big[1:])] == [256, 256, 256, 128, 64, 32, 16, 16]
+    # the largest chunk is sized for an 8-way deal of the frame (auto_chunk: pixels x spp / 2^24 held to [64, 256]): 64 here
+    assert [y - x for x, y in zip(big, big[1:])] == [64] * 15 + [32, 16, 16]
+    c2 = sched(lib.rayz_hip_chunk_schedule, width=1920, height=1080, samples_per_px=256)
+    assert [y - x for x, y in zip(c2, c2[1:])] == [64, 64, 64, 32, 16, 16]
     k4 = sched(lib.rayz_hip_chunk_schedule, width=3840, height=2160, samples_per_px=4096)
-    assert len(k4) - 1 == 20 and k4[-1] - k4[-2] == 16
+    assert len(k4) - 1 == 20 and k4[-1] - k4[-2] == 16 and k4[1] == 256  # 3840x2160x4096: big enough for 256-sample chunks
     p = capi.RenderParams(width=4, height=4, samples_per_px=1 << 30, chunk_spp=1)
     t = tracer.threeSpheres(32, seed=1)
     out = np.zeros((4, 4, 3), dtype=np.float32)
@@ -287,9 +290,13 @@ def test_chunk_count_is_exact_for_every_spp(built, oracle):
         if n < 127:
             assert list(buf[: n + 1]) == list(obuf[: n + 1]), spp
         worst = max(worst, n - spp // 256)
-    assert worst == 9  # the bound the old formula should have used; 497 -> 1 full chunk + 9 in the tail
-    p = capi.RenderParams(width=1920, height=1080, samples_per_px=497)
-    assert lib.rayz_hip_chunk_schedule(C.byref(p), buf, 128) == 10
+    for spp in range(4000, 9001):  # a frame big enough for 256-sample chunks
+        p = capi.RenderParams(width=3840, height=2160, samples_per_px=spp)
+        n = lib.rayz_hip_chunk_schedule(C.byref(p), buf, 128)
+        assert n == olib.rayz_oracle_chunk_schedule(C.byref(p), obuf, 128) and n != 0 and list(buf[: n + 1]) == list(obuf[: n + 1]), spp
+    p = capi.RenderParams(width=3840, height=2160, samples_per_px=30 * 256 + 497)
+    assert lib.rayz_hip_chunk_schedule(C.byref(p), buf, 128) == 30 + 10 == (30 * 256 + 497) // 256 + 9  # the case `spp / 256 + 8` undercounted
+
 
 
 def test_debug_knobs_that_could_hang_a_kernel_are_refused(built):
