@@ -157,12 +157,11 @@ typedef struct RayzRenderParams {
                                 GPU, profiles/r04/multi/tile_rows_ab.log): +8.6 % at 1920x1080 (rows 128..136 per rank) and +1.7 % at
                                 3840x2160 against 1-row interleave, whose perfect row balance (135 each) does not make up for tiles
                                 that span 57 image rows.  Irrelevant when shard_count <= 1 */
-    uint32_t shard_index;    /* this call renders the rows of the tiles (tile = row / tile_rows) this shard owns in the SERPENTINE deal: the
-                                tiles are taken in bands of shard_count; in even bands tile position p goes to shard p, in odd bands to
-                                shard shard_count - 1 - p (0 1 .. N-1, N-1 .. 1 0, 0 1 ..).  A plain round-robin gives shard N-1 rows that lie
-                                (N-1) * tile_rows further down the frame than shard 0's in EVERY band, and cost grows down the frame (sky above,
-                                ground below): measured 9 % between the lightest and the heaviest of 8 shards of the 1080p frame; alternating
-                                the direction cancels that trend (profiles/r04/multi/).  The output is the shard's rows in frame order */
+    uint32_t shard_index;    /* this call renders rows with (row / tile_rows) % shard_count == shard_index.  (Dealing the tiles in alternating
+                                direction per band of shard_count — so that no shard's rows lie systematically lower in the frame, where paths
+                                are longer — was measured in round 4 and NOT adopted: 7.09x instead of 6.91x for the flat list on 8 shards, but
+                                6.99x instead of 7.17x through the BVH and worse at 2 and 4 shards, where it pairs adjacent tiles:
+                                profiles/r04/multi/predicted_scaling_*.log) */
     uint32_t shard_count;    /* 0 or 1 = whole image */
 } RayzRenderParams;
 

@@ -1234,13 +1234,11 @@ static inline u32 shardRows(const RayzRenderParams& p, std::vector<u32>* rows) {
     const u32 tr = p.tile_rows ? p.tile_rows : 8;
     const u32 sc = p.shard_count ? p.shard_count : 1;
     u32 n = 0;
-    for (u32 r = 0; r < p.height; ++r) { // the serpentine deal (include/rayz_hip.h: RayzRenderParams.shard_index)
-        const u32 tile = r / tr, band = tile / sc, pos = tile % sc;
-        if (((band & 1) ? sc - 1 - pos : pos) == p.shard_index) {
+    for (u32 r = 0; r < p.height; ++r)
+        if ((r / tr) % sc == p.shard_index) {
             if (rows) rows->push_back(r);
             ++n;
         }
-    }
     return n;
 }
 

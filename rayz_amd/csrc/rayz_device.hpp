@@ -889,10 +889,7 @@ template <class R, bool kTiled> __device__ __forceinline__ uint32_t place_item(c
     const uint32_t lr = lp / A.width;
     px = lp - lr * A.width;
     const uint32_t tl = lr / A.tile_rows, within = lr - tl * A.tile_rows;
-    // (the serpentine deal of include/rayz_hip.h: this shard's tile of band tl sits at position shard_index, or — odd bands —
-    //  shard_count - 1 - shard_index)
-    const uint32_t pos = (tl & 1u) ? A.shard_count - 1u - A.shard_index : A.shard_index;
-    py = (tl * A.shard_count + pos) * A.tile_rows + within;
+    py = (tl * A.shard_count + A.shard_index) * A.tile_rows + within;
     return k;
 }
 

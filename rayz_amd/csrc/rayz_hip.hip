@@ -1220,8 +1220,7 @@ __global__ __launch_bounds__(256) void unshard_kernel(const T* __restrict__ gath
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)height * row_elems) return;
     const uint32_t y = (uint32_t)(i / row_elems), x = (uint32_t)(i - (size_t)y * row_elems);
-    const uint32_t tile = y / tile_rows, band = tile / n_ranks, pos = tile - band * n_ranks;
-    const uint32_t rank = (band & 1u) ? n_ranks - 1u - pos : pos, local = band * tile_rows + (y - tile * tile_rows); // the serpentine deal
+    const uint32_t tile = y / tile_rows, rank = tile % n_ranks, local = (tile / n_ranks) * tile_rows + (y - tile * tile_rows);
     frame[i] = gathered[((size_t)rank * max_rows + local) * row_elems + x];
 }
 
@@ -1524,11 +1523,8 @@ uint32_t rayz_hip_shard_rows(const RayzRenderParams* p) {
     const uint32_t tr = p->tile_rows ? p->tile_rows : RAYZ_DEFAULT_TILE_ROWS, sc = p->shard_count ? p->shard_count : 1u;
     if (p->shard_index >= sc) return 0;
     uint32_t n = 0;
-    for (uint64_t band = 0;; ++band) { // one tile per band of shard_count tiles, at alternating positions (the serpentine deal)
-        const uint64_t t = band * sc + ((band & 1) ? sc - 1 - p->shard_index : p->shard_index);
-        if (band * sc * tr >= p->height) break;
-        if (t * tr >= p->height) continue; // (this band is the frame's last, partial one and ends before this shard's tile)
-        const uint32_t r0 = (uint32_t)(t * tr);
+    for (uint32_t t = p->shard_index; (uint64_t)t * tr < p->height; t += sc) {
+        const uint32_t r0 = t * tr;
         n += (p->height - r0 < tr) ? p->height - r0 : tr;
     }
     return n;

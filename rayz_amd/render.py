@@ -33,9 +33,7 @@ def shard_row_indices(height: int, tile_rows: int, shard_index: int, shard_count
     tile_rows = tile_rows or 8  # RAYZ_DEFAULT_TILE_ROWS
     shard_count = shard_count or 1
     rows = np.arange(height)
-    tile = rows // tile_rows
-    band, pos = tile // shard_count, tile % shard_count
-    return rows[np.where(band % 2 == 1, shard_count - 1 - pos, pos) == shard_index]  # the serpentine deal (include/rayz_hip.h)
+    return rows[(rows // tile_rows) % shard_count == shard_index]
 
 
 def render_host(scene: capi.SceneDesc, camera: capi.CameraDesc, params: capi.RenderParams):
