@@ -126,9 +126,11 @@ template <class R> struct TraceArgs {
     uint32_t bvh_top_words;   // BVH kernel: u32s of LDS taken by the copy of the tree's top (the per-lane stacks follow)
     uint32_t bvh_big_words;   // BVH kernel: where (in u32s of LDS) the oversized hittables' records are kept, after the stacks
     uint32_t queue_grab;     // work items a wave reserves per atomic on the queue head (kQueueGrab; scheduling only)
+#ifdef RAYZ_EXPERIMENTS // (kept out of the product kernels' argument block: every field costs scalar registers in all of them)
     uint32_t x_words;        // exchange kernel (trace_kernel_bvhx): where (in u32s of LDS) its exchange area starts
     uint32_t x_slots;        //   ray slots per walker wave
-    uint32_t x_cfg;          //   scheduling: exchange when this many lanes finished | shader's minimum batch << 8 | its patience << 16 | its priority << 24
+    uint32_t x_cfg;          //   scheduling: exchange when this many lanes finished | shader's minimum batch << 8 | its patience << 16 | priorities << 24
+#endif
 };
 
 // ---- small helpers -----------------------------------------------------------------------------

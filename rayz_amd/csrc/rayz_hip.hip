@@ -960,7 +960,9 @@ int render_impl(RayzScene* s, const DeviceCtx& ctx, SceneBuffers<R>& b, const Ra
     A.bvh_top_words = (uint32_t)(bvh_top_bytes / sizeof(uint32_t));
     A.bvh_big_words = (uint32_t)((bvh_top_bytes + bvh_stack_bytes) / sizeof(uint32_t));
     A.sc.bvh_top = (uint32_t)bvh_top_bytes; // the walk compares byte offsets
+#ifdef RAYZ_EXPERIMENTS
     A.x_words = (uint32_t)((bvh_top_bytes + bvh_stack_bytes + (b.n_big_leaves ? kBvhBigLdsBytes : 0)) / sizeof(uint32_t));
+#endif
     if (blocks_per_cu < 1) blocks_per_cu = 1;
     uint64_t grid = (uint64_t)ctx.num_cu * blocks_per_cu;
     // (a lane of the two-path kernel holds two items)
