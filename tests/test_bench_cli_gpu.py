@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_bench_json_contract(gpu):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--width", "96", "--spp", "4", "--grid", "4",
                         "--steps", "2", "--warmup", "1", "--cpu-seconds", "0.5"], capture_output=True, text=True,
-                       timeout=600)
+                       timeout=600, env=dict(os.environ, RAYZ_BENCH_MULTI_ALSO_AT_N1="1"))
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1 and len(r.stdout.strip().splitlines()) == 1  # ONE line on stdout: library chatter goes to stderr
@@ -52,6 +52,16 @@ def test_bench_json_contract(gpu):
     assert pr["gather_ms"]["max"] > 0 and d["roofline"]["kernel_ms"] == pr["kernel_ms"]["max"]
     rfm = d["roofline"]["reference_formulation"]
     assert rfm["frac"] is None or rfm["frac"] <= 1
+    # the frame's fingerprint: the same image through the flat list (headline), the BVH, and the code path of the N > 1 BVH block
+    assert len(d["frame_sha256"]) == 64 and d["also"]["bvh_traversal"]["frame_sha256"] == d["frame_sha256"]
+    mb = d["also"]["multi_gpu_bvh_block_at_n1"]
+    assert mb["frame_sha256"] == d["frame_sha256"] and mb["value"] > 0 and mb["launches"]["timed"] == 5
+    assert len(mb["per_rank"]["kernel_ms"]["all"]) == 1 and mb["per_rank"]["gather_ms"]["max"] > 0
+    # every `also` frame is timed over several launches
+    for k, e in d["also"].items():
+        if "launches" in e and "kernel_ms" in e["launches"]:
+            L = e["launches"]
+            assert L["timed"] >= 2 and L["kernel_ms"]["min"] <= L["kernel_ms"]["mean"] <= L["kernel_ms"]["max"], k
     hb = d["roofline"]["hbm"]
     assert hb["algorithmic_bytes"] < hb["workspace_bytes"] * 10 and hb["chunk_sums_per_pixel"] >= 1
 

@@ -14,6 +14,7 @@ def bench(name, t, spp, reps=3, trav=capi.TRAVERSAL_BVH):
     t.samples_per_px = spp
     t.set_gpu(render_seed=1, traversal=trav)
     scene, cam, p = t.scene_desc(), t.camera_desc(), t.params()
+    p.chunk_spp = int(os.environ.get("RAYZ_BENCH_CHUNK_SPP", "0"))  # (uniform chunks instead of the automatic schedule: per-item cost experiments)
     out = torch.empty((p.height, p.width, 3), dtype=torch.float32, device="cuda")
     ds = render.DeviceScene(scene)
     st0 = torch.cuda.current_stream().cuda_stream
