@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """One-path vs two-path BVH kernel (rayz_hip_debug_set BVH_KERNEL) and a sweep of the two-path kernel's scheduling
 thresholds (BVH2_KEEP = service | blocked << 8 | swap << 16 | keep_stepping << 24) on configs 3 / 5 / 2.
-    python tools/bvh2_bench.py [--sweep] [spp3 spp5 spp2]"""
+    bash tools/build_experiments.sh && bash tools/with_lib.sh variants/lib_experiments_s4.so python tools/bvh2_bench.py [--sweep] [spp3 spp5 spp2]
+(the two-path kernel is not in the product library: -DRAYZ_EXPERIMENTS)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

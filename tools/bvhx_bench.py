@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Round-4 experiment: the walker / shader-wave BVH kernel (trace_kernel_bvhx, -DRAYZ_EXPERIMENTS builds, RAYZ_DEBUG_BVH_KERNEL = 3)
 against the product kernel on configs 3, 5 and 2: bit-identical frames required, rates from the library's HIP events.
-    bash tools/with_lib.sh variants/lib_x4.so python tools/bvhx_bench.py [spp3 spp5 spp2] [--cfg=ns,xmin,batch,patience,prio ... (prio = shader | walker N << 2 | walker L/C << 4 | walker exchange << 6)]"""
+    bash tools/build_experiments.sh 4 && bash tools/with_lib.sh variants/lib_experiments_s4.so python tools/bvhx_bench.py [spp3 spp5 spp2] [--cfg=ns,xmin,batch,patience,prio ... (prio = shader | walker N << 2 | walker L/C << 4 | walker exchange << 6)]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

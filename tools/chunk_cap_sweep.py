@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Largest chunk of the automatic (graded) schedule vs whole-frame rate and the rate of ONE GPU's share of an 8-way deal, for the
-BASELINE configs at their own sizes (round 4; RAYZ_DEBUG_CHUNK_CAP experiment knob).   python tools/chunk_cap_sweep.py"""
+BASELINE configs at their own sizes (round 4).  RAYZ_DEBUG_CHUNK_CAP changes the image and exists in -DRAYZ_EXPERIMENTS builds only:
+    bash tools/build_experiments.sh && bash tools/with_lib.sh variants/lib_experiments_s4.so python tools/chunk_cap_sweep.py"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

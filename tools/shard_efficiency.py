@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """How well does ONE GPU's share of an 8-way frame use the GPU?  (round 4)  Config 3 through the BVH and through the flat list:
 whole frame vs shard 0 of 8 (8-row tiles), at the automatic chunk schedule and at uniform chunks (chunk_spp) — a shard has ~1 pixel per
-lane, so the size of the work items decides how evenly the launch ends.   python tools/shard_efficiency.py [spp_bvh spp_flat]"""
+lane, so the size of the work items decides how evenly the launch ends.  (Negative chunk values = the automatic schedule capped at that
+chunk: RAYZ_DEBUG_CHUNK_CAP, -DRAYZ_EXPERIMENTS builds only — bash tools/build_experiments.sh; the product build skips them.)
+    python tools/shard_efficiency.py [spp_bvh spp_flat]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -23,7 +25,12 @@ for trav, spp, name in ((capi.TRAVERSAL_BVH, a[0], "bvh"), (capi.TRAVERSAL_LINEA
         for world in (1, 8):
             p = rdist.shard_params(p0, 0, world)
             p.chunk_spp = max(chunk, 0)
-            render.debug_set(capi.DEBUG_CHUNK_CAP, -chunk if chunk < 0 else -1)
+            try:
+                render.debug_set(capi.DEBUG_CHUNK_CAP, -chunk if chunk < 0 else -1)
+            except capi.RayzHipError:
+                if chunk < 0:
+                    res = None
+                    break
             rows = render.shard_rows(p)
             out = torch.empty((rows, p.width, 3), dtype=torch.float32, device="cuda")
             best = 1e9
@@ -32,6 +39,8 @@ for trav, spp, name in ((capi.TRAVERSAL_BVH, a[0], "bvh"), (capi.TRAVERSAL_LINEA
                 st = ds.sync()
                 best = min(best, st.kernel_ms)
             res.append((best, rows * p.width * spp / best / 1e3))
+        if not res:
+            continue
         print(f"{name} {spp} spp chunk_spp {chunk:3d}: whole frame {res[0][0]:9.2f} ms {res[0][1]:8.1f} Msamples/s | shard 0 of 8 {res[1][0]:9.2f} ms {res[1][1]:8.1f} Msamples/s "
               f"= {100 * res[1][1] / res[0][1]:5.1f} % of the whole-frame rate", flush=True)
 ds.close()
