@@ -365,7 +365,7 @@ def run(args, json_fd):
 
         def extra(name, tr, ds, traversal, precision, spp, shard=(0, 1), workload=None, keep_frame=False):
             """One more frame beside the headline: one untimed launch (uploads, sizes the workspace), then timed launches — at
-            least 3, up to 8 or ~2 s of GPU time for the short frames (an 80 ms frame is not one sample), 2 for frames over 4 s.
+            least 3, up to 8 or ~2 s of GPU time for the short frames (an 80 ms frame is not one sample).
             `value` / `ms_per_step` / `kernel_ms` are the MEAN over the timed launches; `launches` holds min / mean / max."""
             tr.samples_per_px = spp
             tr.set_gpu(render_seed=args.render_seed, traversal=traversal, precision=precision,
@@ -385,7 +385,7 @@ def run(args, json_fd):
                 walls.append(time.perf_counter() - t1)
                 kms.append(st.kernel_ms)
                 n_l, spent = len(walls), sum(walls)
-                if (walls[0] > 4.0 and n_l >= 2) or (n_l >= 3 and (spent > 2.0 or n_l >= 8)):
+                if n_l >= 3 and (spent > 2.0 or n_l >= 8):
                     break
             dt = float(np.mean(walls))
             if keep_frame:

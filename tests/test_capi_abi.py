@@ -280,23 +280,20 @@ def test_chunk_count_is_exact_for_every_spp(built, oracle):
     chunk_schedule() then builds (round 3's `spp / 256 + 8` did, by one, for tails of 256 .. 511 samples: spp = 497 has 10
     chunks).  rayz_hip_chunk_schedule returns 0 when the two disagree; the oracle's independent restatement gives the length."""
     lib, olib = capi.load(), oracle.load()
-    buf, obuf = (C.c_uint32 * 128)(), (C.c_uint32 * 128)()
-    worst = 0
+    buf, obuf = (C.c_uint32 * 640)(), (C.c_uint32 * 640)()
     for spp in list(range(64, 20001)) + [(1 << k) + d for k in range(15, 26) for d in (-1, 0, 1, 255, 256, 257, 497)]:
         p = capi.RenderParams(width=1920, height=1080, samples_per_px=spp)
-        n = lib.rayz_hip_chunk_schedule(C.byref(p), buf, 128)
-        m = olib.rayz_oracle_chunk_schedule(C.byref(p), obuf, 128)
+        n = lib.rayz_hip_chunk_schedule(C.byref(p), buf, 640)
+        m = olib.rayz_oracle_chunk_schedule(C.byref(p), obuf, 640)
         assert n == m and n != 0, (spp, n, m)
-        if n < 127:
-            assert list(buf[: n + 1]) == list(obuf[: n + 1]), spp
-        worst = max(worst, n - spp // 256)
+        k = min(n + 1, 640)
+        assert list(buf[:k]) == list(obuf[:k]) and buf[0] == 0 and (n >= 640 or buf[n] == spp), spp
     for spp in range(4000, 9001):  # a frame big enough for 256-sample chunks
         p = capi.RenderParams(width=3840, height=2160, samples_per_px=spp)
-        n = lib.rayz_hip_chunk_schedule(C.byref(p), buf, 128)
-        assert n == olib.rayz_oracle_chunk_schedule(C.byref(p), obuf, 128) and n != 0 and list(buf[: n + 1]) == list(obuf[: n + 1]), spp
+        n = lib.rayz_hip_chunk_schedule(C.byref(p), buf, 640)
+        assert n == olib.rayz_oracle_chunk_schedule(C.byref(p), obuf, 640) and n != 0 and list(buf[: n + 1]) == list(obuf[: n + 1]), spp
     p = capi.RenderParams(width=3840, height=2160, samples_per_px=30 * 256 + 497)
-    assert lib.rayz_hip_chunk_schedule(C.byref(p), buf, 128) == 30 + 10 == (30 * 256 + 497) // 256 + 9  # the case `spp / 256 + 8` undercounted
-
+    assert lib.rayz_hip_chunk_schedule(C.byref(p), buf, 640) == 30 + 10 == (30 * 256 + 497) // 256 + 9  # the case `spp / 256 + 8` undercounted
 
 
 def test_debug_knobs_that_could_hang_a_kernel_are_refused(built):
