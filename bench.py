@@ -475,7 +475,7 @@ def run(args, json_fd):
         c4 = tracer.randomBouncing(2 * args.width, -args.grid, args.grid, seed=args.scene_seed)
         c4.max_bounces = args.bounces
         ds4 = render.DeviceScene(c4.scene_desc())
-        w4 = f"{c4.info().n_spheres} spheres, {c4.info().width}x{c4.info().height}, rows r % 8 == 0 (one GPU's share of an 8-GPU frame)"
+        w4 = f"{c4.info().n_spheres} spheres, {c4.info().width}x{c4.info().height}, 8-row tiles (row // 8) % 8 == 0 (one GPU's share of an 8-GPU frame)"
         extra("config4_one_gpu_share_bvh", c4, ds4, BVH, F32, 4 * args.spp, shard=(0, 8), workload=w4 + f", {4 * args.spp} spp")
         spp4f = max(1, args.spp // 8)
         extra("config4_one_gpu_share_flat_list", c4, ds4, LIN, F32, spp4f, shard=(0, 8),

@@ -46,7 +46,7 @@ def test_bench_json_contract(gpu):
     for k in ("config2_flat_list", "config2_bvh", "config4_one_gpu_share_bvh", "config4_one_gpu_share_flat_list", "config5_triangle_mesh_bvh"):
         e = d["also"][k]
         assert e["value"] > 0 and e["kernel_ms"] > 0 and e["segments_per_sample"] >= 1 and e["roofline"]["frac"] > 0 and e["workload"], k
-    assert d["also"]["config4_one_gpu_share_bvh"]["spp"] == 16 and "rows r % 8 == 0" in d["also"]["config4_one_gpu_share_bvh"]["workload"]
+    assert d["also"]["config4_one_gpu_share_bvh"]["spp"] == 16 and "(row // 8) % 8 == 0" in d["also"]["config4_one_gpu_share_bvh"]["workload"]
     pr = d["per_rank"]
     assert pr["kernel_ms"]["min"] <= pr["kernel_ms"]["mean"] <= pr["kernel_ms"]["max"] and len(pr["kernel_ms"]["all"]) == 1
     assert pr["gather_ms"]["max"] > 0 and d["roofline"]["kernel_ms"] == pr["kernel_ms"]["max"]
