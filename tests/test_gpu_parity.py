@@ -4,6 +4,7 @@ Mode B is the arithmetic the kernel is specified to perform.  no
 channel against the seeded CPU image; these tests hold the kernel to exact equality (TOL is stated for the
 record and used only in the failure message)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -343,3 +344,55 @@ def test_f32_kernel_is_unbiased_against_f64_and_mode_a(gpu, oracle):
     # per-pixel: differences are noise-shaped (no structured bias): correlation of (f32 - f64) with the image ~ 0
     d = (f32.astype(np.float64) - f64).ravel()
     assert abs(np.corrcoef(d, f64.ravel())[0, 1]) < 0.1
+
+
+def test_f64_kernel_samples_mode_a_distribution_per_pixel(gpu, oracle):
+    """The unpinned rows of the parity table (hitInner, every scatter, reflectance, bounceRay: the reference has no vector for them)
+    hang on a STATISTICAL link between the kernel arithmetic and the reference as written.  In the suite that link used to be a
+    64x36 frame; this is tools/fidelity_mode_a.py at 480x270: mode A (f64, the reference's BVH and recursion, sequential xoshiro
+    streams, tmin 1e-10) renders 192 spp with per-pixel variances on the host's cores, the f64 kernel (the reference's scalar type
+    and tmin) 4096 spp on the GPU — the image means agree within 3.5 standard errors, every one of 9 row bands within 4.5, and the
+    per-pixel z-scores are centred (|median| < 0.03; measured −0.004) with the spread sampling noise gives them (interquartile range = a unit
+    normal's within 10 %; measured 1.002) — no structured bias in 129,600 pixels.  The f32 default differs by the reference's own tmin artefact and is held to 1e-3 relative."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    W, SPP_A = 480, 192
+    t = tracer.randomBouncing(W, seed=42)
+    scene, cam = t.scene_desc(), t.camera_desc()
+    pa = t.params()
+    pa.precision, pa.tmin, pa.samples_per_px = capi.PRECISION_F64, 1e-10, SPP_A
+    H = pa.height
+    threads = max(1, min(os.cpu_count() or 1, 16))
+    a, sq = np.zeros((H, W, 3)), np.zeros((H, W, 3))
+
+    def work(k):
+        st = t.rng_state().copy()
+        st[0] ^= np.uint64((0x9E3779B97F4A7C15 * (k + 1)) & 0xFFFFFFFFFFFFFFFF)
+        for r in range(k, H, threads):
+            img, s2, _ = oracle.render_a(scene, cam, pa, st, row_begin=r, row_end=r + 1, want_sumsq=True)
+            a[r], sq[r] = img[0], s2[0]
+
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(work, range(threads)))
+    var = np.maximum(sq / SPP_A - a ** 2, 0) / SPP_A  # variance of mode A's pixel means
+    t.samples_per_px = 4096
+    t.set_gpu(render_seed=5, precision=capi.PRECISION_F64, tmin=1e-10)
+    g, st = gpu.render_host(scene, cam, t.params())
+    var_tot = var * (1 + SPP_A / 4096)  # + the GPU frame's own noise (same per-sample variance, 4096 samples)
+    se = np.sqrt(var_tot.sum()) / a.size
+    assert abs(a.mean() - g.mean()) < 3.5 * se, (a.mean(), g.mean(), se)
+    for b in np.array_split(np.arange(H), 9):
+        zb = (a[b].mean() - g[b].mean()) / (np.sqrt(var_tot[b].sum()) / a[b].size)
+        assert abs(zb) < 4.5, (int(b[0]), zb)
+    ok = var > 1e-10
+    z = ((a - g) / np.sqrt(np.maximum(var_tot, 1e-14)))[ok]
+    # (the variance of a pixel is ESTIMATED from mode A's own samples: where those missed the rare bright paths it is too
+    #  small and z is large — the spread is measured robustly, by the interquartile range)
+    q1, q3 = np.percentile(z, [25, 75])
+    robust = (q3 - q1) / 1.349
+    print(f"per-pixel z over {ok.sum()} values: median {np.median(z):+.4f}, IQR sigma {robust:.3f}, std {z.std():.3f}, "
+          f"|z| > 4: {(np.abs(z) > 4).mean():.2e}, |z| > 8: {(np.abs(z) > 8).mean():.2e}")
+    assert abs(np.median(z)) < 0.03 and 0.9 < robust < 1.12 and (np.abs(z) > 8).mean() < 5e-3  # measured: -0.004, 1.002, 8e-4
+    t.set_gpu(render_seed=6, precision=capi.PRECISION_F32, tmin=1e-3)
+    f, _ = gpu.render_host(scene, cam, t.params())
+    assert abs(f.astype(np.float64).mean() / g.mean() - 1) < 1e-3
