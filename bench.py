@@ -172,6 +172,8 @@ def launch_ranks(args) -> None:
     import subprocess
 
     have = visible_gpu_count()
+    if os.environ.get("RAYZ_BENCH_TEST_SHARED_GPU") == "1":
+        have = None  # (test hook, see run(): the ranks share device 0 over gloo; the line says so)
     if have is not None and have < args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible; refusing to measure fewer")
     with socket.socket() as s:
@@ -215,6 +217,12 @@ def run(args, json_fd):
 
     from rayz_amd import capi, render, tracer
 
+    # RAYZ_BENCH_TEST_SHARED_GPU=1: the test suite's hook for boxes with ONE GPU — every rank uses device 0 and the collectives run
+    # over gloo, so that the whole N > 1 code path of this file (sharding, gather, per-rank table, frame hash, the BVH block)
+    # executes before a real N-GPU node runs it.  The line it prints says so (`test_hook`) and is no measurement of N GPUs.
+    shared_gpu = os.environ.get("RAYZ_BENCH_TEST_SHARED_GPU") == "1"
+    if shared_gpu:
+        local_rank = 0
     if local_rank >= torch.cuda.device_count():
         raise SystemExit(f"bench.py: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) are visible")
     if not torch.cuda.is_available():
@@ -223,14 +231,17 @@ def run(args, json_fd):
     backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if shared_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         backend = dist.get_backend()
         if dist.get_world_size() != args.gpus:
             raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
         # one rank per physical GPU: every rank must sit on a different device
         ident = [None] * world
         dist.all_gather_object(ident, (os.uname().nodename, str(torch.cuda.get_device_properties(local_rank).uuid)))
-        if len(set(ident)) != world:
+        if len(set(ident)) != world and not shared_gpu:
             raise SystemExit(f"bench.py: ranks share a GPU: {ident}")
     render.init(local_rank)
 
@@ -553,13 +564,16 @@ def run(args, json_fd):
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "frame_sha256": frame_sha256,
+            **({"test_hook": "RAYZ_BENCH_TEST_SHARED_GPU: all ranks on ONE GPU, collectives over gloo — exercises the N > 1 code path, measures nothing"}
+               if shared_gpu else {}),
             "dtype": "f32" if args.precision == "f32" else "f64",
             "data": "synthetic",
             "config": {
                 "workload": f"randomBouncing grid [-{args.grid},{args.grid}) = {info.n_spheres} spheres "
                             f"({n_static} static, {n_moving} moving), {W}x{H}, {args.spp} spp, {args.bounces} bounces, "
                             f"{args.traversal} traversal, scene seed {args.scene_seed}, render seed {args.render_seed}",
-                "parallelism": f"rows dealt in interleaved 8-row tiles x{world} + one RCCL all_gather per frame" if world > 1 else "1 GPU",
+                "parallelism": (f"rows dealt in interleaved 8-row tiles x{world} + one {'RCCL' if backend == 'nccl' else backend} all_gather per frame"
+                                if world > 1 else "1 GPU"),
                 "collective_backend": backend, "collective_world_size": world if world > 1 else None,
                 "segments_per_sample": frame_segments / samples_per_step,
                 "arithmetic": ("f32 path state and reject test, f64 candidate roots (DESIGN.md 4.3), tmin 1e-3"

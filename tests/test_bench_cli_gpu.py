@@ -66,6 +66,31 @@ def test_bench_json_contract(gpu):
     assert hb["algorithmic_bytes"] < hb["workspace_bytes"] * 10 and hb["chunk_sums_per_pixel"] >= 1
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_ranks_on_one_gpu_print_the_same_frame_hash(gpu, world):
+    """bench.py's N > 1 path — row deal, gather, per-rank table, frame hash, the N > 1 BVH block — with two and three ranks (an uneven deal: 7 row
+    tiles) under torch.distributed.run.  The box has ONE GPU, so the test hook puts every rank on it and runs the collectives over gloo: the line
+    says `test_hook`, its numbers mean nothing, but its `frame_sha256` must equal the one-rank run's (the image does not depend on N),
+    and the BVH block's as well."""
+    base = [os.path.join(ROOT, "bench.py"), "--width", "96", "--spp", "4", "--grid", "4", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    one = subprocess.run([sys.executable, *base, "--gpus", "1", "--no-also"], capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
+    two = subprocess.run([sys.executable, *base, "--gpus", str(world)], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, RAYZ_BENCH_TEST_SHARED_GPU="1"))
+    assert two.returncode == 0, two.stderr[-3000:]
+    lines = [l for l in two.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1  # rank 0 prints, the others stay silent
+    d2 = json.loads(lines[0])
+    assert d2["n_gpus"] == world and "test_hook" in d2 and d2["config"]["collective_backend"] == "gloo"
+    assert d2["frame_sha256"] == d1["frame_sha256"] and len(d1["frame_sha256"]) == 64
+    pr = d2["per_rank"]
+    assert len(pr["kernel_ms"]["all"]) == world and min(pr["kernel_ms"]["all"]) > 0 and len(pr["segments"]) == world
+    assert abs(sum(pr["segments"]) - d1["config"]["segments_per_sample"] * 96 * 54 * 4) < 0.5  # the shards' segments add up to the frame's
+    b = d2["also"]["bvh_traversal"]
+    assert b["frame_sha256"] == d1["frame_sha256"] and b["value"] > 0 and len(b["per_rank"]["kernel_ms"]["all"]) == world
+
+
 def test_cli_renders_reference_scene(gpu, tmp_path):
     exe = os.path.join(ROOT, "rayz_amd", "host", "rayz")
     out = tmp_path / "out.ppm"
