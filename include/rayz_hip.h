@@ -333,8 +333,9 @@ typedef enum RayzKatOp {
     RAYZ_KAT_REFRACT = 0,     /* in: unit_dir[0..2] normal[3..5] eta[6]            out: dir[0..2]       src/material.zig:189-194 */
     RAYZ_KAT_REFLECTANCE = 1, /* in: cos[0] ri[1]                                  out: r[0]            src/material.zig:179-183 */
     RAYZ_KAT_GET_RAY = 2,     /* in: look_from px_du px_dv px_origin defocus_u defocus_v [0..17] defocus[18] px[19] py[20]
-                                     n_u[21] (an integer in [0, 26], RAYZ_ERR_BAD_ARG otherwise) u[22..]; n_u = 0 is NOT
-                                     getRay(px,py,null): the kernel always draws
+                                     n_u[21] (an integer in [0, 26], or -1; RAYZ_ERR_BAD_ARG otherwise) u[22..];
+                                     n_u = -1 is getRay(px, py, null) — no jitter, lens centre, time 0: the call of the reference's own
+                                     "get ray" test, src/renderer.zig:129-149; n_u = 0 draws 0.5 everywhere (the kernels always draw)
                                  out: origin[0..2] dir[3..5] time[6] draws[7]                           src/camera.zig:59-90 */
     RAYZ_KAT_BOX_HIT = 3,     /* in: low[0..2] high[3..5] origin[6..8] dir[9..11] tmin[12] tmax[13] format[26] (the node record
                                      the box is tested in: 0 = 16-bit plane indices, non-zero = f32 planes)

@@ -1386,10 +1386,17 @@ template <class R> static void katB(uint32_t op, const double* a, double* r) {
         CamB<R> cam;
         cam.from = v3(0), cam.du = v3(3), cam.dv = v3(6), cam.pxo = v3(9), cam.defu = v3(12), cam.defv = v3(15);
         cam.defocus = a[18] != 0.0;
-        ListRng<R> g{a + 22, (u32)a[21], 0u};
+        ListRng<R> g{a + 22, a[21] < 0.0 ? 0u : (u32)a[21], 0u};
         V<R> o, d;
         R time;
-        cameraRay<R>(cam, g, (u32)a[19], (u32)a[20], o, d, time);
+        if (a[21] < 0.0) { // n_u = -1: getRay(px, py, null) in mode B's operation order (no draw, lens centre, time 0)
+            const R x = (R)(u32)a[19], y = (R)(u32)a[20];
+            o = cam.from;
+            d = {(fm(cam.dv.x, y, cam.du.x * x) + cam.pxo.x) - o.x, (fm(cam.dv.y, y, cam.du.y * x) + cam.pxo.y) - o.y,
+                 (fm(cam.dv.z, y, cam.du.z * x) + cam.pxo.z) - o.z};
+            time = R(0);
+        } else
+            cameraRay<R>(cam, g, (u32)a[19], (u32)a[20], o, d, time);
         put3(0, o);
         put3(3, d);
         r[6] = (double)time;
@@ -1542,8 +1549,9 @@ static void katA(uint32_t op, const double* a, double* r) {
         c.look_from = v3(a), c.px_du = v3(a + 3), c.px_dv = v3(a + 6), c.px_origin = v3(a + 9);
         c.defocus_u = v3(a + 12), c.defocus_v = v3(a + 15);
         c.defocus = a[18] != 0.0;
-        A::ListRng g{a + 22, (u32)a[21], 0u};
-        const Ray ray = c.getRay((size_t)a[19], (size_t)a[20], &g);
+        A::ListRng g{a + 22, a[21] < 0.0 ? 0u : (u32)a[21], 0u};
+        const Ray ray = a[21] < 0.0 ? c.getRay<A::ListRng>((size_t)a[19], (size_t)a[20], nullptr) // n_u = -1: the reference's rng == null
+                                    : c.getRay((size_t)a[19], (size_t)a[20], &g);
         put3(0, ray.origin);
         put3(3, ray.dir);
         r[6] = ray.time;

@@ -110,7 +110,10 @@ inline void build(std::vector<Item>& h, size_t si, size_t ei, FlatBvh& out, uint
 // to the lower axis and the lower position).  `budget` = levels left: the per-lane stacks in LDS are sized by the depth, so
 // a node that could no longer finish with halvings alone is split at its median instead (never deeper than the reference's
 // tree + kSahExtraDepth).
-constexpr size_t kSweepMax = 4096;
+#ifndef RAYZ_SAH_SWEEP_MAX
+#define RAYZ_SAH_SWEEP_MAX 4096
+#endif
+constexpr size_t kSweepMax = RAYZ_SAH_SWEEP_MAX;
 constexpr uint32_t kSahBins = 64, kSahExtraDepth = 4;
 inline double halfArea(const Box& b) {
     const double x = b.hi[0] - b.lo[0], y = b.hi[1] - b.lo[1], z = b.hi[2] - b.lo[2];

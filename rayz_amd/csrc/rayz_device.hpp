@@ -836,6 +836,18 @@ __device__ __forceinline__ void camera_ray(const DevCamera<R>& cam, G& g, uint32
     time = uniform<R>(g);
 }
 
+// `getRay(px, py, null)` (src/camera.zig:59-77 with rng == null: the pixel's centre, the lens centre, time 0) — the form the
+// reference's own "get ray" test calls (src/renderer.zig:129-149).  No path ever takes it (the kernels always draw); it exists for
+// the known-answer entry, in the same operation order as camera_ray above.
+template <class R> __device__ __forceinline__ void camera_ray_no_rng(const DevCamera<R>& cam, uint32_t px, uint32_t py, V<R>& o, V<R>& d, R& time) {
+    const R x = (R)px, y = (R)py;
+    o = {cam.from[0], cam.from[1], cam.from[2]};
+    d.x = (fm(cam.dv[0], y, cam.du[0] * x) + cam.pxo[0]) - o.x;
+    d.y = (fm(cam.dv[1], y, cam.du[1] * x) + cam.pxo[1]) - o.y;
+    d.z = (fm(cam.dv[2], y, cam.du[2] * x) + cam.pxo[2]) - o.z;
+    time = R(0);
+}
+
 // ---- per-path state of one of a lane's rays, and the steps every trace kernel shares ---------------------
 template <class R> struct PathState {
     Pcg32 g;
@@ -2523,10 +2535,11 @@ template <class R> __global__ __launch_bounds__(64) void kat_kernel(uint32_t op,
         }
         cam.defocus = a[18] != 0.0 ? 1u : 0u;
         cam._pad = 0;
-        ListRng g{a + 22, (uint32_t)a[21], 0u};
+        ListRng g{a + 22, a[21] < 0.0 ? 0u : (uint32_t)a[21], 0u};
         V<R> o, d;
         R time;
-        camera_ray<R>(cam, g, (uint32_t)a[19], (uint32_t)a[20], o, d, time);
+        if (a[21] < 0.0) camera_ray_no_rng<R>(cam, (uint32_t)a[19], (uint32_t)a[20], o, d, time); // n_u = -1: getRay(px, py, null)
+        else camera_ray<R>(cam, g, (uint32_t)a[19], (uint32_t)a[20], o, d, time);
         put3(0, o);
         put3(3, d);
         r[6] = (double)time;

@@ -1654,8 +1654,10 @@ int rayz_hip_kat(uint32_t op, uint32_t precision, const double* in, uint32_t n, 
             if (op == RAYZ_KAT_GET_RAY || op == RAYZ_KAT_SCATTER) {
                 const int at = op == RAYZ_KAT_GET_RAY ? 21 : 16;
                 const double nu = a[at];
-                if (!(nu >= 0 && nu <= RAYZ_KAT_IN_STRIDE - (at + 1) && nu == std::floor(nu)))
-                    return fail(RAYZ_ERR_BAD_ARG, "record %u: n_u = %g is not an integer in [0, %d]", i, nu, RAYZ_KAT_IN_STRIDE - (at + 1));
+                const bool no_rng = op == RAYZ_KAT_GET_RAY && nu == -1.0; // getRay(px, py, null)
+                if (!no_rng && !(nu >= 0 && nu <= RAYZ_KAT_IN_STRIDE - (at + 1) && nu == std::floor(nu)))
+                    return fail(RAYZ_ERR_BAD_ARG, "record %u: n_u = %g is not an integer in [0, %d]%s", i, nu, RAYZ_KAT_IN_STRIDE - (at + 1),
+                                op == RAYZ_KAT_GET_RAY ? " (or -1: no generator)" : "");
             }
             if (op == RAYZ_KAT_BOX_HIT) { // the box as a scene upload would hold it (S = this ray's origin, B = this box), in the format a[26] names
                 rayz_bvh::Box bx;

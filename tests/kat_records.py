@@ -34,13 +34,14 @@ def refract_reference():  # src/material.zig:213-223
     return rec, np.array([0.144881, 0.144881, -0.978784])
 
 
-def get_ray_reference(camera_desc):  # src/renderer.zig:129-149 (focus sqrt(12), defocus 0: SURVEY.md §4)
+def get_ray_reference(camera_desc, no_rng=False):  # src/renderer.zig:129-149 (focus sqrt(12), defocus 0: SURVEY.md §4)
+    """no_rng: n_u = -1, i.e. getRay(px, py, null) exactly as the reference's test calls it; otherwise n_u = 0 (every draw 0.5)."""
     rec = blank(2)
     c = camera_desc
     for i, (px, py) in enumerate([(0, 0), (112, 199)]):
         rec[i, 0:18] = np.concatenate([np.array(x) for x in (c.look_from, c.px_du, c.px_dv, c.px_origin, c.defocus_u,
                                                                c.defocus_v)])
-        rec[i, 18], rec[i, 19], rec[i, 20], rec[i, 21] = c.defocus, px, py, 0  # no list: every draw is 0.5 = no jitter
+        rec[i, 18], rec[i, 19], rec[i, 20], rec[i, 21] = c.defocus, px, py, (-1 if no_rng else 0)  # 0: no list, every draw is 0.5 = no jitter
     want = np.array([[-0.935834, 0.815856, -7.75169], [-0.998817, -4.18732, -2.8115]])
     return rec, want
 

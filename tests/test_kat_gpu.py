@@ -22,6 +22,14 @@ def test_device_functions_on_the_reference_vectors(gpu, oracle, prec):
     rec, want = K.get_ray_reference(cam)  # src/renderer.zig:129-149
     got = gpu.kat(capi.KAT_GET_RAY, rec, prec)
     assert got[:, 0:3].tolist() == [[-2, 2, 1]] * 2 and got[:, 3:6] == pytest.approx(want, rel=1e-5)
+    # .. and the reference's own call, getRay(px, py, null) (src/camera.zig:59-77 with rng == null; n_u = -1): no draw, time 0,
+    # the same ray as the all-0.5 jitter gives — bit for bit — and bit-identical to mode B; mode A agrees to f64 / f32 rounding
+    rec0, _ = K.get_ray_reference(cam, no_rng=True)
+    got0 = gpu.kat(capi.KAT_GET_RAY, rec0, prec)
+    assert got0[:, 7].tolist() == [0, 0] and got0[:, 6].tolist() == [0, 0] and got[:, 7].tolist() == [3, 3]  # draws made, time
+    assert np.array_equal(got0[:, 0:6], got[:, 0:6]) and got0[:, 3:6] == pytest.approx(want, rel=1e-5)
+    assert np.array_equal(got0, oracle.kat_b(capi.KAT_GET_RAY, rec0, prec))
+    assert oracle.kat_a(capi.KAT_GET_RAY, rec0)[:, 3:6] == pytest.approx(want, rel=1e-5)
     rec, want = K.box_hit_reference()  # src/hit.zig:247-279
     assert gpu.kat(capi.KAT_BOX_HIT, rec, prec)[:, 0].tolist() == want.tolist()
 
@@ -96,16 +104,20 @@ def test_conservative_filter_on_the_device(gpu, oracle):
 
 def test_kat_refuses_a_uniform_list_that_leaves_the_record(gpu):
     """n_u is the caller's: a list that would run past the record's 48 doubles (the device reads u[0 .. n_u)) is refused on
-    the host with RAYZ_ERR_BAD_ARG, as is a negative, fractional or NaN count."""
+    the host with RAYZ_ERR_BAD_ARG, as is a negative (but for GET_RAY's -1), fractional or NaN count."""
     for op, at, cap in ((capi.KAT_GET_RAY, 21, 26), (capi.KAT_SCATTER, 16, 31)):
         rec = K.blank(3)
         rec[:, at] = cap
         gpu.kat(op, rec)  # the largest list that fits
-        for bad in (cap + 1, -1, 2.5, float("nan"), 1e30):
+        # (-1 is GET_RAY's "no generator" = getRay(px, py, null), accepted there and only there)
+        for bad in (cap + 1, -2, -1.5, 2.5, float("nan"), 1e30) + (() if op == capi.KAT_GET_RAY else (-1,)):
             rec = K.blank(3)
             rec[2, at] = bad
             with pytest.raises(capi.RayzHipError, match="n_u"):
                 gpu.kat(op, rec)
+    rec = K.blank(3)
+    rec[:, 21] = -1
+    assert gpu.kat(capi.KAT_GET_RAY, rec)[:, 7].tolist() == [0, 0, 0]  # no draw made
 
 
 @pytest.mark.parametrize("prec", [F32, F64])

@@ -126,6 +126,25 @@ def test_get_ray(oracle):
         assert got == pytest.approx(want, rel=1e-5)
 
 
+def test_get_ray_without_a_generator_through_the_kat_records(oracle):
+    """The same vector through the known-answer record format with n_u = -1 (= `getRay(px, py, null)`, the call the reference's test
+    makes): mode A (the reference's function with rng == null) and mode B (the kernel arithmetic, what rayz_hip_kat's device code is
+    held to bit for bit in tests/test_kat_gpu.py) both reproduce it; no draw is consumed and time is 0."""
+    import kat_records as K
+
+    cam = capi.CameraDesc()
+    oracle.load().rayz_oracle_camera_init(90, 12 ** 0.5, 0, d3([-2, 2, 1]), d3([0, 0, -1]), d3([0, 1, 0]), 225, 400, cam)
+    rec, want = K.get_ray_reference(cam, no_rng=True)
+    assert rec[:, 21].tolist() == [-1, -1]
+    for got in (oracle.kat_a(capi.KAT_GET_RAY, rec), oracle.kat_b(capi.KAT_GET_RAY, rec, capi.PRECISION_F64),
+                oracle.kat_b(capi.KAT_GET_RAY, rec, capi.PRECISION_F32)):
+        assert got[:, 0:3].tolist() == [[-2, 2, 1]] * 2 and got[:, 3:6] == pytest.approx(want, rel=1e-5)
+        assert got[:, 6].tolist() == [0, 0] and got[:, 7].tolist() == [0, 0]  # time 0, no draw
+    jit, _ = K.get_ray_reference(cam)  # n_u = 0: every draw 0.5 — the same ray (x + 0 exactly), but three draws and time 0.5
+    a0, a5 = oracle.kat_a(capi.KAT_GET_RAY, rec), oracle.kat_a(capi.KAT_GET_RAY, jit)
+    assert np.array_equal(a0[:, 0:6], a5[:, 0:6]) and a5[:, 6].tolist() == [0.5, 0.5] and a5[:, 7].tolist() == [3, 3]
+
+
 # ---- src/image.zig:32-39 + src/vec.zig:79-93: sqrt (0 for non-positive), clamp, truncating *255 -----
 @pytest.mark.parametrize("rgb,want", [
     ([0.0, 1.0, 4.0], [0, 255, 255]),
