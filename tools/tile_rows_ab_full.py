@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""tile_rows A/B at BASELINE config 3's FULL size (1024 spp), flat list and BVH: every shard of an 8-way deal on this one GPU, slowest
+shard = the frame time of an 8-GPU node before the gather (round 4; the 256-spp version is tools/tile_rows_ab.py).
+    python tools/tile_rows_ab_full.py"""
 import os, sys
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
