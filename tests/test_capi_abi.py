@@ -318,3 +318,31 @@ def test_debug_knobs_that_could_hang_a_kernel_are_refused(built):
     finally:
         for k in (capi.DEBUG_BVH_KEEP, capi.DEBUG_QUEUE_GRAB, capi.DEBUG_BVH_KERNEL, capi.DEBUG_BVH2_KEEP, capi.DEBUG_LDS_PAD):
             lib.rayz_hip_debug_set(k, -1)
+
+
+def test_automatic_schedule_invariants_over_random_frames(built, oracle):
+    """Properties of the automatic chunk schedule over random frame sizes: it partitions [0, spp); chunk sizes never
+    grow along the schedule (big items first, the queue ends in short ones); the largest chunk is a power of two, at most 256, at most
+    spp / 2, and — round 4 — at most 1/8 of a lane's share of an 8-way deal over 2^18-lane GPUs (pixels x spp / 2^24) unless that would
+    go below 64; small frames and low sample counts use uniform 16; library and oracle agree; the shard fields never matter."""
+    lib, olib = capi.load(), oracle.load()
+    rng = np.random.default_rng(11)
+    buf, obuf = (C.c_uint32 * 4096)(), (C.c_uint32 * 4096)()
+    for _ in range(600):
+        w, h = int(rng.integers(1, 6000)), int(rng.integers(1, 4000))
+        spp = int(2 ** rng.uniform(0, 13.5))
+        p = capi.RenderParams(width=w, height=h, samples_per_px=spp, shard_index=int(rng.integers(0, 3)), shard_count=3, tile_rows=int(rng.integers(0, 9)))
+        n = lib.rayz_hip_chunk_schedule(C.byref(p), buf, 4096)
+        assert n == olib.rayz_oracle_chunk_schedule(C.byref(p), obuf, 4096) and 0 < n < 4096, (w, h, spp, n)
+        a = list(buf[: n + 1])
+        assert a == list(obuf[: n + 1]) and a[0] == 0 and a[-1] == spp
+        sizes = [y - x for x, y in zip(a, a[1:])]
+        assert all(s > 0 for s in sizes)
+        if w * h < (1 << 19) or spp < 64:
+            assert all(s == 16 for s in sizes[:-1]) and sizes[-1] <= 16
+            continue
+        assert all(x >= y for x, y in zip(sizes, sizes[1:])), (w, h, spp, sizes)
+        big = sizes[0]
+        assert big & (big - 1) == 0 and big <= 256 and big <= spp // 2
+        assert big <= max(64, (w * h * spp) >> 24), (w, h, spp, big)
+        assert min(sizes[:-1]) >= 16  # (only the last chunk may be a remainder)
