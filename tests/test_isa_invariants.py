@@ -66,3 +66,38 @@ def test_no_instruction_touches_the_node_fetch_registers_in_flight(tmp_path):
                 assert k - i < 80, (name, "no second wait after the split one")
             blocks += 1
     assert blocks >= 2 * 4  # two steps per wave-level decision in each one-path kernel
+
+
+def test_product_kernels_stay_off_their_codegen_cliffs(tmp_path):
+    """Properties of the compiled gfx950 code that a refactor can lose without any test noticing a wrong pixel (only a slower frame):
+    no vector register of a trace kernel is spilled to scratch in the f32 kernels (the BVH kernels sit at 123 – 128 VGPRs, 4 waves per
+    SIMD), the BVH kernels' shading pass fetches its tables with global, not flat, loads (round 4: behind the empty asm that pins the
+    table pointers the compiler no longer knows the address space unless it is told), the retired experiment kernels are not in the
+    product build, and the flat-list kernel's scalar spills stay where round 4 left them (its scan loop lives on an allocation edge)."""
+    from rayz_amd import _build
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    asm = tmp_path / "dev.s"
+    flags = [f for f in _build.HIPFLAGS if f not in ("-fPIC", "-Wall", "-Wextra")]
+    subprocess.run([hipcc, *flags, "--cuda-device-only", "-S", "-o", str(asm), os.path.join(ROOT, "rayz_amd", "csrc", "rayz_hip.hip")],
+                   check=True, capture_output=True, timeout=600)
+    text = asm.read_text()
+    assert "trace_kernel_bvh2" not in text and "trace_kernel_bvhx" not in text
+    meta = {}
+    for m in re.finditer(r"\.name:\s+(\S+)\n((?:\s+\.\w+:.*\n)+)", text):
+        fields = dict(re.findall(r"\.(\w+):\s+(\S+)", m.group(2)))
+        meta[m.group(1)] = fields
+    traces = {k: v for k, v in meta.items() if "trace_kernel" in k}
+    assert len(traces) == 6, sorted(traces)  # flat f32 / f64, BVH f32 / f64 x two node-record formats
+    for name, f in traces.items():
+        f64 = "IdL" in name  # (TraceArgs<double>)
+        assert int(f["vgpr_count"]) <= 128, (name, f["vgpr_count"])
+        assert int(f["vgpr_spill_count"]) <= (1 if f64 else 0), (name, f["vgpr_spill_count"])
+        if "bvh" not in name and not f64:
+            assert int(f["sgpr_spill_count"]) <= 80, (name, f["sgpr_spill_count"])  # 70 in round 4 (63 in round 3)
+    bodies = _kernels(text)
+    for name, L in bodies.items():
+        assert not any(re.match(r"\s*flat_load", l) for l in L), f"{name}: a flat_load is back in the BVH kernel (shade's table pointers lost their address space)"
+        assert not any(re.match(r"\s*scratch_(load|store)", l) for l in L) or "IdL" in name, f"{name}: scratch traffic in an f32 BVH kernel"
