@@ -101,3 +101,20 @@ def test_product_kernels_stay_off_their_codegen_cliffs(tmp_path):
     for name, L in bodies.items():
         assert not any(re.match(r"\s*flat_load", l) for l in L), f"{name}: a flat_load is back in the BVH kernel (shade's table pointers lost their address space)"
         assert not any(re.match(r"\s*scratch_(load|store)", l) for l in L) or "IdL" in name, f"{name}: scratch traffic in an f32 BVH kernel"
+
+
+def test_experiments_build_still_compiles(tmp_path):
+    """The retired experiment kernels (two paths per lane, round 3; walker / shader waves, round 4) live behind -DRAYZ_EXPERIMENTS with
+    their tools (tools/build_experiments.sh): they are evidence, and evidence that no longer compiles cannot be re-measured.  Device code
+    only, all three shader-wave counts of the exchange kernel are instantiable."""
+    from rayz_amd import _build
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    flags = [f for f in _build.HIPFLAGS if f not in ("-fPIC", "-Wall", "-Wextra")]
+    asm = tmp_path / "x.s"
+    subprocess.run([hipcc, *flags, "-DRAYZ_EXPERIMENTS", "-DRAYZ_BVHX_SHADERS=5", "--cuda-device-only", "-S", "-o", str(asm),
+                    os.path.join(ROOT, "rayz_amd", "csrc", "rayz_hip.hip")], check=True, capture_output=True, timeout=600)
+    text = asm.read_text()
+    assert "trace_kernel_bvh2" in text and "trace_kernel_bvhx" in text
