@@ -8,6 +8,8 @@ import torch
 from rayz_amd import capi, render, tracer
 
 render.init(0)
+if os.environ.get("RAYZ_BENCH_QUEUE_GRAB"):
+    render.debug_set(capi.DEBUG_QUEUE_GRAB, int(os.environ["RAYZ_BENCH_QUEUE_GRAB"]))  # (experiments: items reserved per queue atomic)
 
 
 def bench(name, t, spp, reps=3, trav=capi.TRAVERSAL_BVH):
