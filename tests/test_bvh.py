@@ -243,7 +243,7 @@ def test_gpu_bvh_equals_flat_list_on_the_whole_config3_frame(gpu):
 
 
 @pytest.mark.gpu
-def test_gpu_bvh_equals_flat_list_at_baseline_config3_in_full(gpu):
+def test_gpu_bvh_equals_flat_list_at_baseline_config3_in_full(gpu, oracle):
     """BASELINE.json configs[2] exactly — 10,003 spheres, 1920x1080, 1024 spp, 50 bounces: 2.1e9 paths, 6.3e9 segments
     through the flat list (the headline kernel, ~9 s) and through the BVH on the device: the same image bit for bit, the
     same segment count, no non-finite pixel."""
@@ -255,6 +255,15 @@ def test_gpu_bvh_equals_flat_list_at_baseline_config3_in_full(gpu):
     flat, fst = gpu.render_host(t.scene_desc(), t.camera_desc(), t.params())
     assert np.array_equal(bvh, flat) and bst.segments == fst.segments and np.isfinite(flat).all()
     assert fst.primary_rays == 1920 * 1080 * 1024 and 2.9 < fst.segments / fst.primary_rays < 3.0
+    # .. and 32 scattered pixels of it by the oracle at the full 1024 spp (through its own BVH walk: the same nearest hits), bit for
+    # bit: pins the summation tree of the metric's own schedule (64 x 15, 32, 16, 16: DESIGN.md 4.6) on the metric's own frame
+    from helpers import assert_images_equal
+
+    rng = np.random.default_rng(4)
+    pix = np.unique(np.concatenate([rng.integers(0, 1920 * 1080, 28), [0, 1919, 1920 * 1079, 1920 * 1080 - 1]])).astype(np.uint32)
+    t.set_gpu(traversal=capi.TRAVERSAL_BVH)
+    want, _ = oracle.render_b(t.scene_desc(), t.camera_desc(), t.params(), pixels=pix)
+    assert_images_equal(flat.reshape(-1, 3)[pix], want, "config 3 at full size and full spp, oracle spot pixels")
 
 
 @pytest.mark.gpu
